@@ -1,0 +1,222 @@
+/*
+ * vdr.h — C ABI of libvdr.so, the MI355X-native (gfx950) ViT dense-descriptor /
+ * CLS-feature forward path for the larosi/vit-deep-radiomics pipeline.
+ *
+ * The reference has no FFI of its own: its boundary for this path is the
+ * torch.nn.Module call protocol at three sites:
+ *
+ *   R1  src/tfds_dense_descriptor.py:51-67    model = load_model(name, path); model.model_name
+ *   R2  src/tfds_dense_descriptor.py:122-129  model.image_encoder(x) / model.patch_embed(x)
+ *   R3  src/models_archs.py:141-147           model(x[B,S,D]) -> (logits[B,C], cls[B,D])
+ *
+ * Every entry point below says which of those call sites (or which torch op
+ * invoked underneath them) it replaces.  The Python shim in
+ * vit-deep-radiomics_amd/vdr/ binds these symbols with ctypes and re-creates
+ * R1-R3 on top of them (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / C++ types cross this boundary;
+ *   - every function returns 0 on success or a negative vdr_status; nothing
+ *     throws; vdr_last_error() gives the text of the last failure on a handle
+ *     (or of the last failure of a handle-less call when passed NULL);
+ *   - device pointers are gfx950 HBM addresses of the device the handle was
+ *     created on; the caller owns inputs, outputs and the workspace and keeps
+ *     them alive until the stream has drained; the library owns only its packed
+ *     weights;
+ *   - all work is enqueued on the hipStream_t passed as `void* stream`
+ *     (NULL = the null stream); no call synchronises the device;
+ *   - a handle is bound to one device and is not thread-safe (one per rank).
+ *   - there is NO CPU path in this library: with no HIP device every compute
+ *     call fails with VDR_ERR_NO_DEVICE.
+ */
+#ifndef VDR_H_
+#define VDR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDR_ABI_VERSION 1
+
+typedef enum {
+  VDR_OK = 0,
+  VDR_ERR_INVALID = -1,      /* bad argument / shape / config               */
+  VDR_ERR_NO_DEVICE = -2,    /* no gfx950 HIP device visible                */
+  VDR_ERR_HIP = -3,          /* a HIP runtime call failed                   */
+  VDR_ERR_UNKNOWN_NAME = -4, /* vdr_set_weight: name not part of the config */
+  VDR_ERR_WORKSPACE = -5,    /* workspace too small                         */
+  VDR_ERR_INCOMPLETE = -6,   /* forward called before every weight was set  */
+  VDR_ERR_UNSUPPORTED = -7   /* config outside what the kernels cover       */
+} vdr_status;
+
+typedef enum { VDR_F32 = 0, VDR_BF16 = 1 } vdr_dtype;
+
+typedef enum { VDR_ACT_GELU = 0, /* exact erf GELU: models_archs.py:133, timm/DINOv2 Mlp */
+               VDR_ACT_SWIGLU = 1 /* DINOv2 ViT-g SwiGLUFFN (w12 / w3)                   */
+} vdr_act;
+
+/* What vdr_forward writes. */
+typedef enum {
+  VDR_OUT_CLS = 0,         /* [B, D]      final-LN(x)[:,0,:]     (models_archs.py:147 contract)     */
+  VDR_OUT_DENSE = 1,       /* [B, n, D]   final-LN(x)[:,1:,:]    (tfds_dense_descriptor.py:130-133) */
+  VDR_OUT_PATCH_EMBED = 2, /* [B, n, D]   conv patchify only     (tfds_dense_descriptor.py:128)     */
+  VDR_OUT_TOKENS = 3       /* [B, N, D]   every token after the last block + final LN (if any)      */
+} vdr_out_mode;
+
+/* Geometry of one frozen ViT.  Mirrors the constructor arguments the reference
+ * passes to its third-party ViTs (tfds_dense_descriptor.py:87,104) and to
+ * nn.TransformerEncoderLayer (models_archs.py:130-135). */
+typedef struct {
+  int32_t img;        /* square input side in pixels (224, 336, 896 ...); 0 for a token model */
+  int32_t patch;      /* patch side p (14, 16); 0 for a token model                           */
+  int32_t in_chans;   /* 3                                                                    */
+  int32_t dim;        /* D                                                                    */
+  int32_t heads;      /* H ; D / H must be 64                                                 */
+  int32_t layers;     /* L                                                                    */
+  int32_t mlp_hidden; /* F (GELU: fc1 out; SwiGLU: hidden of w3's input)                      */
+  int32_t act;        /* vdr_act                                                              */
+  int32_t pre_ln;     /* 1: x += f(LN(x)) + final norm (timm/DINOv2/SAM);                     */
+                      /* 0: x = LN(x + f(x)), no final norm (nn.TransformerEncoderLayer)      */
+  int32_t layerscale; /* 1: DINOv2 ls1/ls2 gamma                                              */
+  int32_t has_cls;    /* 1: a learned cls_token row is prepended                              */
+  int32_t has_pos;    /* 1: learned pos_embed [1,N,D] is added                                */
+  int32_t input_ln;   /* 1: LayerNorm applied to the assembled tokens before block 0          */
+                      /*    (models_archs.py:145)                                             */
+  float ln_eps;       /* 1e-6 timm/DINOv2/SAM, 1e-5 torch default (models_archs.py:136)       */
+  int32_t micro_batch;/* images per internal pass (0 = library default sized to the 256 MiB   */
+                      /* Infinity Cache); results do not depend on it                         */
+  int32_t reserved[4];
+} vdr_config;
+
+typedef struct vdr_model* vdr_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+
+/* ABI version of the loaded library (== VDR_ABI_VERSION it was built with). */
+int vdr_abi_version(void);
+
+/* Number of visible gfx950 devices (0 when there is none; never fails). */
+int vdr_device_count(void);
+
+/* Replaces: model construction in load_dinov2 / load_medsam
+ * (tfds_dense_descriptor.py:70-107) and TransformerNoduleClassifier.__init__
+ * (models_archs.py:128-139).  Binds the handle to HIP device `device`. */
+int vdr_create(const vdr_config* cfg, int device, vdr_handle* out);
+void vdr_destroy(vdr_handle h);
+const char* vdr_last_error(vdr_handle h);
+
+/* Replaces: load_state_dict (models_archs.py:32-35) / sam_model_registry(path)
+ * (tfds_dense_descriptor.py:104).  `name` uses the timm/DINOv2 state_dict keys
+ * listed in SURVEY.md §8a ("patch_embed.proj.weight", "cls_token", "pos_embed",
+ * "blocks.{i}.norm1.weight", "blocks.{i}.attn.qkv.weight", "blocks.{i}.attn.proj.bias",
+ * "blocks.{i}.ls1.gamma", "blocks.{i}.mlp.fc1.weight", "blocks.{i}.mlp.w12.weight",
+ * "norm.weight", "input_norm.weight" ...).  `host` points to `numel` contiguous fp32
+ * values in HOST memory in the PyTorch layout of that key; the library converts,
+ * repacks and uploads (synchronously; this is load time, not the hot path). */
+int vdr_set_weight(vdr_handle h, const char* name, const float* host, const int64_t* shape, int ndim);
+
+/* Number of weight tensors the config expects, and the i-th expected name. */
+int vdr_num_weights(vdr_handle h);
+const char* vdr_weight_name(vdr_handle h, int i);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+
+/* Bytes of device workspace vdr_forward / vdr_forward_tokens need for `batch`
+ * images (token models: `batch` sequences of `seq` tokens, seq ignored otherwise). */
+int vdr_workspace_bytes(vdr_handle h, int batch, int seq, size_t* out);
+
+/* Replaces: model.image_encoder(x) / model.patch_embed(x)
+ * (tfds_dense_descriptor.py:123,128) followed by the CLS / patch-token slice
+ * (models_archs.py:147; tfds_dense_descriptor.py:130-133), batched.
+ *   images : device, NCHW [batch, in_chans, img, img], dtype in_dtype, values as the
+ *            reference feeds them (raw [0,1]; no mean/std normalisation is applied)
+ *   out    : device, shape by out_mode, dtype out_dtype, C-contiguous, row b = image b */
+int vdr_forward(vdr_handle h, const void* images, int in_dtype, int batch, void* out, int out_mode,
+                int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces: TransformerNoduleClassifier.forward up to x[:,0,:]
+ * (models_archs.py:141-147): tokens [batch, seq, D] fp32/bf16 on device ->
+ * [cls ; tokens] -> (input LN) -> L blocks -> out by out_mode
+ * (VDR_OUT_CLS -> [batch, D]; VDR_OUT_TOKENS -> [batch, seq+has_cls, D]). */
+int vdr_forward_tokens(vdr_handle h, const void* tokens, int in_dtype, int batch, int seq, void* out,
+                       int out_mode, int out_dtype, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- single operators (the torch ops the reference invokes underneath R2/R3) ------------ */
+/* Exposed so that each HIP kernel is parity-tested against its torch op through
+ * this ABI (tests/test_ops_gpu.py).  All pointers are device pointers. */
+
+/* F.layer_norm(x, (D,), gamma, beta, eps)  — nn.LayerNorm at models_archs.py:136,145 and
+ * norm1/norm2/norm of the ViT blocks.  x [rows, D] in_dtype -> y [rows, D] out_dtype;
+ * gamma/beta fp32 [D]. */
+int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma,
+                     const float* beta, int64_t rows, int D, float eps, void* stream);
+
+/* epilogues of vdr_op_linear */
+typedef enum {
+  VDR_EPI_BIAS = 0,      /* y = xW^T + b                      F.linear                          */
+  VDR_EPI_BIAS_GELU = 1, /* y = gelu_erf(xW^T + b)            linear1 + activation (a9)         */
+  VDR_EPI_BIAS_RESID = 2,/* y = resid + gamma*(xW^T + b)      out_proj / linear2 + residual     */
+  VDR_EPI_SWIGLU = 3     /* y[:, :N/2] = silu(a)*b, (a,b) = split(xW^T + b)  DINOv2 SwiGLUFFN   */
+} vdr_epilogue;
+
+/* F.linear(x, W, b) (+ fused epilogue) — nn.Linear inside nn.MultiheadAttention /
+ * TransformerEncoderLayer (models_archs.py:130-135), attn.qkv / attn.proj / mlp.fc1 / mlp.fc2.
+ *   x [M, K] bf16, W [N, K] bf16 (PyTorch layout), bias fp32 [N] or NULL,
+ *   resid [M, N] bf16 (EPI_BIAS_RESID; may alias y), gamma fp32 [N] or NULL (LayerScale),
+ *   y [M, N] bf16 (EPI_SWIGLU: [M, N/2]).  K % 64 == 0, N % 8 == 0.
+ *   `variant` selects the tile configuration (0 = library default). */
+int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid,
+                  const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
+                  void* stream);
+
+/* F.scaled_dot_product_attention over a packed qkv activation — the core of
+ * nn.MultiheadAttention (models_archs.py:130) / Attention.forward of the ViTs.
+ *   qkv [batch*seq, 3*H*64] bf16, row = token, columns [q | k | v] each [H, 64]
+ *   out [batch*seq, H*64] bf16;  softmax(q k^T / 8) v per (batch, head), no mask. */
+int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
+                     void* stream);
+
+/* nn.Conv2d(in_chans, D, kernel=p, stride=p) + flatten(2).transpose(1,2) — DINOv2 PatchEmbed,
+ * the op called at tfds_dense_descriptor.py:128.
+ *   images NCHW [batch, C, img, img] in_dtype; W bf16 [D, Kp] (C*p*p columns zero-padded to
+ *   Kp = roundup(C*p*p, 64)); bias fp32 [D]; pos fp32 [n(+1), D] or NULL;
+ *   col: device scratch of batch*n*Kp bf16;
+ *   y bf16: row (b*row_stride + row_offset + i) for patch i of image b, plus pos[row_offset+i]. */
+int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const float* bias,
+                       const float* pos, void* col, void* y, int batch, int C, int img, int p, int D,
+                       int row_stride, int row_offset, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+
+/* Kernel classes timed by the built-in HIP-event profiler. */
+typedef enum {
+  VDR_K_IM2COL = 0,
+  VDR_K_GEMM_PATCH = 1,
+  VDR_K_LAYERNORM = 2,
+  VDR_K_GEMM_QKV = 3,
+  VDR_K_ATTENTION = 4,
+  VDR_K_GEMM_PROJ = 5,
+  VDR_K_GEMM_FC1 = 6,
+  VDR_K_GEMM_FC2 = 7,
+  VDR_K_FINAL_LN = 8,
+  VDR_K_ASSEMBLE = 9,
+  VDR_K_COUNT = 10
+} vdr_kernel_class;
+
+/* When enabled, vdr_forward* brackets every launch with hipEventRecord on the
+ * caller's stream.  vdr_profile_read synchronises on those events and returns,
+ * per class, the summed milliseconds, the launch count and the algorithmic
+ * FLOPs and bytes of those launches since the last read / reset. */
+int vdr_profile_enable(vdr_handle h, int on);
+int vdr_profile_read(vdr_handle h, double* ms, int64_t* launches, double* flops, double* bytes,
+                     int n /* = VDR_K_COUNT */);
+const char* vdr_kernel_class_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDR_H_ */

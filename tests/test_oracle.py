@@ -1,0 +1,87 @@
+"""CPU: the oracle against the golden vectors.
+
+postln_*.npz were produced by the REFERENCE's models_archs.TransformerNoduleClassifier
+(tests/golden/make_golden.py); vit_hf_* / dinov2_hf_* by the in-container transformers
+classes (architecture cross-check only).  Tolerance: fp32, max-abs <= 2e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "refconf", "cfg1"])
+def test_postln_matches_reference_class(golden_dir, tag):
+    g = _load(golden_dir, f"postln_{tag}.npz")
+    cfg = vo.postln_cfg(int(g["dim"]), int(g["heads"]), int(g["layers"]), int(g["ffn"]))
+    w = vo.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = vo.make_tokens(int(g["batch"]), int(g["seq"]), int(g["dim"]), seed=int(g["xseed"]))
+    # the seeded generators reproduce what the fixture was made from
+    np.testing.assert_array_equal(x[0, :2, :8].numpy(), g["x_probe"])
+    np.testing.assert_array_equal(w["blocks.0.attn.qkv.weight"][:2, :8].numpy(), g["w_probe"])
+    o = vo.forward_tokens(cfg, w, x)
+    assert o["cls"].shape == (int(g["batch"]), int(g["dim"]))
+    assert np.abs(o["cls"].numpy() - g["cls"]).max() <= TOL
+    logits = vo.mlp_head(o["cls"], torch.from_numpy(g["head.classifier.dense1.weight"]),
+                         torch.from_numpy(g["head.classifier.dense1.bias"]),
+                         torch.from_numpy(g["head.classifier.dense2.weight"]),
+                         torch.from_numpy(g["head.classifier.dense2.bias"]))
+    assert np.abs(logits.numpy() - g["logits"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["vit_hf_tiny", "vit_hf_p16", "dinov2_hf_tiny"])
+def test_preln_matches_transformers_crosscheck(golden_dir, name):
+    g = _load(golden_dir, name + ".npz")
+    sw = name.startswith("dinov2")
+    cfg = vo.VitCfg(int(g["img"]), int(g["patch"]), 3, int(g["dim"]), int(g["heads"]), int(g["layers"]),
+                    int(g["ffn"]), act="swiglu" if sw else "gelu", layerscale=sw, ln_eps=1e-6)
+    w = vo.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = vo.make_images(cfg, int(g["batch"]), seed=int(g["xseed"]))
+    o = vo.forward_images(cfg, w, x)
+    assert np.abs(o["tokens"].numpy() - g["tokens"]).max() <= 5e-5
+    np.testing.assert_array_equal(o["cls"].numpy(), o["tokens"][:, 0].numpy())
+    np.testing.assert_array_equal(o["dense"].numpy(), o["tokens"][:, 1:].numpy())
+
+
+def test_patch_embed_is_conv2d():
+    cfg = vo.VitCfg(56, 14, 3, 32, 1, 1, 64)
+    w = vo.make_weights(cfg, seed=5, scale=0.1)
+    x = vo.make_images(cfg, 2, seed=1)
+    ref = torch.nn.functional.conv2d(x, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], stride=14)
+    ref = ref.flatten(2).transpose(1, 2)
+    got = vo.patch_embed(x, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], 14)
+    assert (got - ref).abs().max() <= 1e-5
+
+
+def test_sdpa_matches_torch():
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(2, 3, 37, 64) for _ in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    assert (vo.sdpa(q, k, v) - ref).abs().max() <= 1e-5
+
+
+def test_emulated_bf16_close_to_fp32():
+    cfg = vo.VitCfg(32, 8, 3, 64, 1, 2, 128)
+    w = vo.make_weights(cfg, seed=2)
+    x = vo.make_images(cfg, 2, seed=2)
+    a = vo.forward_images(cfg, w, x)["cls"]
+    b = vo.forward_images(cfg, w, x, emulate_bf16=True)["cls"]
+    rel = ((a - b).norm() / a.norm()).item()
+    assert rel < 2e-2
+
+
+def test_flops_formula_matches_survey():
+    # ViT-B/16 35.13 GFLOP/img, ViT-Ti/16 2.51, ViT-L/14@336 381.9, ViT-g/14 598.8
+    assert abs(vo.flops_per_image(vo.CONFIGS["vit_base16_224"]) / 1e9 - 35.13) < 0.02
+    assert abs(vo.flops_per_image(vo.CONFIGS["vit_tiny16_224"]) / 1e9 - 2.51) < 0.01
+    assert abs(vo.flops_per_image(vo.CONFIGS["vit_large14_336"]) / 1e9 - 381.9) < 0.2
+    assert abs(vo.flops_per_image(vo.CONFIGS["dinov2_giant14_224"]) / 1e9 - 598.8) < 0.3
