@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the ViT-B/16 224^2 bf16 CLS-feature forward path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+[256,3,224,224] bf16 per GPU -> vdr_forward (patch-embed, 12 pre-LN blocks, final LN + CLS slice)
+-> [256,768] fp32 CLS features; for N > 1 each rank processes its own 256 images (weak scaling,
+BASELINE config 3 = 8 x 256) and ONE all-gather (RCCL over xGMI) reassembles the [N*256,768]
+feature matrix inside the step.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel class (by summed time) of the timed region, timed with HIP events
+recorded by libvdr on the stream the kernels are launched on (vdr_profile_*): achieved = algorithmic
+FLOPs of those launches / their summed duration; peak = 2.5 PFLOP/s dense bf16 MFMA.
+cpu_baseline: the CPU fp32 oracle (oracle/vit_oracle.py, a port — the reference's Python never
+travels) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vit-deep-radiomics_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+GEMM_CLASSES = ("gemm_patch", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention")
+
+
+def cpu_baseline(cfg_name, seconds_target=12.0):
+    """Oracle forward on the host cores; bounded sample (batch 8 per run, ~10-20 s total)."""
+    from oracle import vit_oracle as vo
+    cfg = vo.CONFIGS[cfg_name]
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    w = vo.make_weights(cfg, seed=1)
+    b = 8
+    x = vo.make_images(cfg, b, seed=0)
+    vo.forward_images(cfg, w, x)  # warm-up
+    runs, t0 = 0, time.perf_counter()
+    while True:
+        vo.forward_images(cfg, w, x)
+        runs += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or runs >= 50:
+            break
+    return {"value": round(runs * b / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{runs} runs x batch {b} of {cfg_name} fp32 (oracle/vit_oracle.forward_images), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--model", type=str, default="vit_base16_224")
+    ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clean-timing", action="store_true",
+                    help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libvdr has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import vdr
+    from vdr.dist import all_gather_rows
+    from oracle import vit_oracle as vo  # weights/images generators + cpu_baseline only
+
+    ocfg = vo.CONFIGS[a.model]
+    model = vdr.load_model(a.model, weights=vo.make_weights(ocfg, seed=1), device=dev, micro_batch=a.micro_batch)
+    eng = model.engine
+    B, D = a.batch, ocfg.dim
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g).to(torch.bfloat16).to(dev)  # synthetic [0,1)
+    total = B * world
+    feats = torch.empty((total, D), dtype=torch.float32, device=dev)  # final row-ordered [N, D] matrix
+    mine = feats[rank * B:(rank + 1) * B]
+
+    def step():
+        eng.forward_into(images, mine, vdr.OUT_CLS)  # writes this rank's rows of the gather buffer
+        if world > 1:
+            dist.all_gather_into_tensor(feats, mine)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    eng.profile(not a.clean_timing)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if a.clean_timing:  # second, event-bracketed pass for the per-kernel numbers
+        eng.profile(True)
+        for _ in range(a.steps):
+            step()
+        sync()
+        prof = eng.profile_read()
+        eng.profile(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    assert torch.isfinite(feats).all()
+
+    if rank == 0:
+        flops_img = vo.flops_per_image(ocfg)
+        ms = dt / a.steps * 1e3
+        ips = total * a.steps / dt
+        kern = {}
+        for k, v in prof.items():
+            e = {"ms_per_step": round(v["ms"] / a.steps, 4), "launches_per_step": v["launches"] // a.steps}
+            if v["flops"] > 0:
+                e["TFLOP/s"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
+            e["GB/s_algorithmic"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+            kern[k] = e
+        dom = max((k for k in prof if k in GEMM_CLASSES), key=lambda k: prof[k]["ms"])
+        dv = prof[dom]
+        ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(dv["ms"] / dv["launches"], 4),
+                "flops_per_launch": dv["flops"] / dv["launches"],
+                "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof.values()) / a.steps, 3)}
+        out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
+               else f"images/sec, {a.model} CLS-feature extraction",
+               "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"{a.model} {ocfg.img}^2 bf16, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32"
+                                      + (", all-gather of feature matrix" if world > 1 else ""),
+                          "global_batch": total, "parallelism": f"batch-shard dp{world}",
+                          "weights": "random-init (seed 1)", "micro_batch": a.micro_batch},
+               "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
+               "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
+               "roofline": roof, "kernels": kern}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

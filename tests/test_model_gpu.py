@@ -1,0 +1,219 @@
+"""GPU parity of the full forward path through the C ABI (vdr_forward / vdr_forward_tokens) against
+the CPU fp32 oracle and the committed golden vectors.
+
+Stated tolerances (SURVEY.md §8d "Parity gate"):
+  * bf16 HIP path vs the fp32 oracle on identical seeded inputs: per-row cosine >= 0.999 and
+    relative L2 <= 1e-2 (CLS), <= 2e-2 (dense tokens);
+  * bf16 HIP path vs the oracle run with bf16 rounding emulated at the same store points:
+    relative L2 <= 4e-3 — this isolates kernel arithmetic from the precision choice;
+  * golden vectors produced by the reference's own TransformerNoduleClassifier: same gates.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def _min_cos(a, b):
+    a, b = a.double().reshape(-1, a.shape[-1]), b.double().reshape(-1, b.shape[-1])
+    return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
+
+
+def _engine(cfg: vo.VitCfg, w, micro_batch=0):
+    import vdr
+    vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
+                       mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
+                       has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
+                       micro_batch=micro_batch)
+    e = vdr.Engine(vc)
+    e.load_weights(w)
+    return e
+
+
+def _gate(got, ref, ref_emul, l2_fp32, l2_emul, what):
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), what
+    r32, re, c = _rel_l2(got, ref), _rel_l2(got, ref_emul), _min_cos(got, ref)
+    print(f"{what}: relL2 vs fp32 {r32:.3e}  vs bf16-emulated {re:.3e}  min cos {c:.6f}")
+    assert c >= 0.999, f"{what}: min cosine {c}"
+    assert r32 <= l2_fp32, f"{what}: rel L2 vs fp32 oracle {r32}"
+    assert re <= l2_emul, f"{what}: rel L2 vs bf16-emulating oracle {re}"
+
+
+SMALL = {
+    "tiny_p8": vo.VitCfg(32, 8, 3, 64, 1, 2, 128),
+    "p16_d128": vo.VitCfg(64, 16, 3, 128, 2, 3, 512),
+    "p14_d192": vo.VitCfg(56, 14, 3, 192, 3, 2, 768),
+    "dinov2_swiglu_ls": vo.VitCfg(56, 14, 3, 128, 2, 2, 320 + 64, act="swiglu", layerscale=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_small_vit_all_outputs(name):
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=3, scale=0.05)
+    x = vo.make_images(cfg, 5, seed=4)
+    ref = vo.forward_images(cfg, w, x)
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    xd = x.cuda()
+    _gate(e.forward(xd, vdr.OUT_CLS), ref["cls"], emu["cls"], 1e-2, 4e-3, f"{name} cls")
+    _gate(e.forward(xd, vdr.OUT_DENSE), ref["dense"], emu["dense"], 2e-2, 4e-3, f"{name} dense")
+    _gate(e.forward(xd, vdr.OUT_TOKENS), ref["tokens"], emu["tokens"], 2e-2, 4e-3, f"{name} tokens")
+    _gate(e.forward(xd, vdr.OUT_PATCH_EMBED), ref["patch_embed"], emu["patch_embed"], 1e-2, 4e-3, f"{name} patch_embed")
+    # bf16 input images and bf16 outputs take the same path
+    d16 = e.forward(xd.to(torch.bfloat16), vdr.OUT_DENSE, torch.bfloat16)
+    assert d16.dtype == torch.bfloat16 and _rel_l2(d16.float().cpu(), ref["dense"]) < 3e-2
+
+
+def test_micro_batching_does_not_change_results():
+    import vdr
+    cfg = SMALL["p16_d128"]
+    w = vo.make_weights(cfg, seed=5, scale=0.05)
+    x = vo.make_images(cfg, 7, seed=6).cuda()
+    a = _engine(cfg, w).forward(x, vdr.OUT_CLS)
+    b = _engine(cfg, w, micro_batch=3).forward(x, vdr.OUT_CLS)
+    assert torch.equal(a, b)
+    one = _engine(cfg, w).forward(x[2:3], vdr.OUT_CLS)
+    assert torch.equal(a[2:3], one), "a row must not depend on what else is in the batch"
+
+
+def test_vit_tiny16_224_config1():
+    """BASELINE config 1 geometry (ViT-Ti/16 224^2, batch 8 -> [8,192] CLS) on the GPU vs the oracle."""
+    import vdr
+    cfg = vo.CONFIGS["vit_tiny16_224"]
+    w = vo.make_weights(cfg, seed=1)
+    x = vo.make_images(cfg, 8, seed=0)
+    ref = vo.forward_images(cfg, w, x)
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    got = e.forward(x.cuda(), vdr.OUT_CLS)
+    assert got.shape == (8, 192) and got.dtype == torch.float32
+    _gate(got, ref["cls"], emu["cls"], 1e-2, 4e-3, "vit_tiny cls")
+    _gate(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emu["dense"], 2e-2, 4e-3, "vit_tiny dense")
+
+
+def test_vit_base16_224_headline_config():
+    """BASELINE config 2 geometry (ViT-B/16 224^2); batch 4 keeps the CPU oracle to seconds."""
+    import vdr
+    cfg = vo.CONFIGS["vit_base16_224"]
+    w = vo.make_weights(cfg, seed=1)
+    x = vo.make_images(cfg, 4, seed=0)
+    ref = vo.forward_images(cfg, w, x)
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    got = e.forward(x.cuda().to(torch.bfloat16), vdr.OUT_CLS)
+    assert got.shape == (4, 768)
+    _gate(got, ref["cls"], emu["cls"], 1e-2, 5e-3, "vit_base cls")
+
+
+@pytest.mark.parametrize("tag", ["tiny", "refconf", "cfg1"])
+def test_golden_reference_class_tokens(golden_dir, tag):
+    """models_archs.TransformerNoduleClassifier golden vectors (made by the reference itself)."""
+    import vdr
+    g = np.load(os.path.join(golden_dir, f"postln_{tag}.npz"), allow_pickle=False)
+    dim, heads, layers, ffn = int(g["dim"]), int(g["heads"]), int(g["layers"]), int(g["ffn"])
+    cfg = vo.postln_cfg(dim, heads, layers, ffn)
+    w = vo.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = vo.make_tokens(int(g["batch"]), int(g["seq"]), dim, seed=int(g["xseed"]))
+    emu = vo.forward_tokens(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    cls = e.forward_tokens(x.cuda(), vdr.OUT_CLS)
+    _gate(cls, torch.from_numpy(g["cls"]), emu["cls"], 1.5e-2, 5e-3, f"golden postln_{tag} cls")
+    # the drop-in class: (logits, cls) tuple, state_dict in the reference's own key names
+    sd = {"cls_token": w["cls_token"], "norm.weight": w["input_norm.weight"], "norm.bias": w["input_norm.bias"]}
+    for i in range(layers):
+        s, d = f"blocks.{i}.", f"transformer_encoder.layers.{i}."
+        sd[d + "self_attn.in_proj_weight"] = w[s + "attn.qkv.weight"]
+        sd[d + "self_attn.in_proj_bias"] = w[s + "attn.qkv.bias"]
+        sd[d + "self_attn.out_proj.weight"] = w[s + "attn.proj.weight"]
+        sd[d + "self_attn.out_proj.bias"] = w[s + "attn.proj.bias"]
+        sd[d + "linear1.weight"], sd[d + "linear1.bias"] = w[s + "mlp.fc1.weight"], w[s + "mlp.fc1.bias"]
+        sd[d + "linear2.weight"], sd[d + "linear2.bias"] = w[s + "mlp.fc2.weight"], w[s + "mlp.fc2.bias"]
+        for n in ("norm1", "norm2"):
+            sd[d + n + ".weight"], sd[d + n + ".bias"] = w[s + n + ".weight"], w[s + n + ".bias"]
+    for k in ("dense1.weight", "dense1.bias", "dense2.weight", "dense2.bias"):
+        sd["classifier." + k] = torch.from_numpy(g["head.classifier." + k])
+    m = vdr.TransformerNoduleClassifier(dim, ffn, heads, 2, layers, sd)
+    logits, cls2 = m(x.cuda())
+    assert logits.shape == (int(g["batch"]), 2) and cls2.shape == (int(g["batch"]), dim)
+    assert torch.equal(cls2, cls)
+    err = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
+    assert err < 3e-2, f"logits max abs err {err}"
+
+
+@pytest.mark.parametrize("name", ["vit_hf_tiny", "vit_hf_p16"])
+def test_golden_transformers_crosscheck(golden_dir, name):
+    import vdr
+    g = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    cfg = vo.VitCfg(int(g["img"]), int(g["patch"]), 3, int(g["dim"]), int(g["heads"]), int(g["layers"]), int(g["ffn"]))
+    w = vo.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = vo.make_images(cfg, int(g["batch"]), seed=int(g["xseed"]))
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    got = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
+    _gate(got, torch.from_numpy(g["tokens"]), emu["tokens"], 2e-2, 4e-3, name)
+
+
+def test_reference_boundary_protocol():
+    """R1/R2: load_model(...).model_name, .patch_embed(x) -> [B,n,D], .image_encoder(x) -> [B,D,h,w],
+    get_dense_descriptor(model, img) -> (h,w,D) numpy — as tfds_dense_descriptor.py:110-139 uses them;
+    torch.cuda.empty_cache() between calls (reference :137) must not break the engine."""
+    import vdr
+    cfg = vo.CONFIGS["vit_tiny16_224"]
+    w = vo.make_weights(cfg, seed=2)
+    model = vdr.load_model("vit_tiny16_224", weights=w)
+    assert model.model_name == "vit_tiny16_224"
+    x = vo.make_images(cfg, 2, seed=9)
+    ref = vo.forward_images(cfg, w, x)
+    pe = model.patch_embed(x.cuda())
+    assert pe.shape == (2, 196, 192) and pe.is_cuda
+    torch.cuda.empty_cache()
+    enc = model.image_encoder(x.cuda())
+    assert enc.shape == (2, 192, 14, 14)
+    model.model_name = "dinov2"   # the reference assigns the attribute after construction
+    f = vdr.get_dense_descriptor(model, x[0].numpy())
+    assert f.shape == (14, 14, 192) and f.dtype == np.float32
+    assert _rel_l2(torch.from_numpy(f).reshape(196, 192), ref["patch_embed"][0]) < 1e-2
+    model.model_name = "medsam"
+    f2 = vdr.get_dense_descriptor(model, x[0].numpy())
+    assert f2.shape == (14, 14, 192)
+    assert _rel_l2(torch.from_numpy(f2).reshape(196, 192), ref["dense"][0]) < 2e-2
+    d = vdr.extract_dense(model, x.cuda())
+    assert d.shape == (2, 14, 14, 192)
+    np.testing.assert_array_equal(d[0], f2)
+    with pytest.raises(ValueError):
+        model.patch_embed(torch.zeros(1, 3, 100, 100).cuda())
+    with pytest.raises(KeyError):
+        vdr.load_model("vit_tiny16_224", weights={k: v for k, v in w.items() if k != "norm.bias"})
+
+
+def test_full_batch_properties_at_baseline_size():
+    """Size-independent properties at BASELINE config-2 size (B=256 would need minutes of CPU oracle):
+    (i) batch-permutation equivariance, (ii) duplicate images give bitwise-identical rows,
+    (iii) a B=256 run agrees row-for-row with B=3 runs of the same images."""
+    import vdr
+    cfg = vo.CONFIGS["vit_base16_224"]
+    w = vo.make_weights(cfg, seed=1)
+    e = _engine(cfg, w)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(256, 3, 224, 224, generator=g).to(torch.bfloat16).cuda()
+    x[17] = x[3]
+    out = e.forward(x, vdr.OUT_CLS)
+    assert out.shape == (256, 768) and torch.isfinite(out).all()
+    assert torch.equal(out[17], out[3])
+    perm = torch.randperm(256, generator=g).cuda()
+    out_p = e.forward(x[perm], vdr.OUT_CLS)
+    assert torch.equal(out_p, out[perm])
+    small = e.forward(x[100:103], vdr.OUT_CLS)
+    assert torch.equal(small, out[100:103])

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at the BASELINE config-2 shapes (ViT-B/16, B=256: M = 50432).
+Interleaved rounds in one process (guide §5.4 rule 24), random data (rule 25)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "vit-deep-radiomics_amd"))
+import torch  # noqa: E402
+
+import vdr  # noqa: E402
+from vdr import ops  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq", type=int, default=197)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--variants", type=str, default="0,2,3")
+    ap.add_argument("--out", type=str, default="")
+    a = ap.parse_args()
+    M, D = a.batch * a.seq, a.dim
+    H = D // 64
+    res = {}
+    dev = "cuda"
+    torch.manual_seed(0)
+    shapes = {"qkv": (3 * D, D, vdr.EPI_BIAS), "proj": (D, D, vdr.EPI_BIAS_RESID), "fc1": (4 * D, D, vdr.EPI_BIAS_GELU),
+              "fc2": (D, 4 * D, vdr.EPI_BIAS_RESID)}
+    for name, (N, K, epi) in shapes.items():
+        x = torch.randn(M, K, device=dev).bfloat16()
+        W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        b = torch.randn(N, device=dev)
+        r = torch.randn(M, N, device=dev).bfloat16() if epi == vdr.EPI_BIAS_RESID else None
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        for v in [int(s) for s in a.variants.split(",")]:
+            med, mn = timeit(lambda: ops.linear(x, W, b, resid=r, epilogue=epi, variant=v, out=out))
+            tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
+            res[f"gemm_{name}_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
+            print(f"gemm {name:5s} M{M} N{N} K{K} variant {v}: {med:8.3f} ms (min {mn:.3f})  {tf:7.1f} TFLOP/s", flush=True)
+        del x, W, out
+    qkv = torch.randn(M, 3 * D, device=dev).bfloat16()
+    for v in (0, 1):
+        med, mn = timeit(lambda: ops.attention(qkv, a.batch, a.seq, H, variant=v))
+        tf = 4.0 * a.seq * a.seq * 64 * H * a.batch / (med * 1e-3) / 1e12
+        res[f"attention_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
+        print(f"attention B{a.batch} N{a.seq} H{H} variant {v}: {med:8.3f} ms (min {mn:.3f})  {tf:7.1f} TFLOP/s", flush=True)
+    x = torch.randn(M, D, device=dev).bfloat16()
+    g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    med, mn = timeit(lambda: ops.layernorm(x, g, b, 1e-6))
+    gbs = 4.0 * M * D / (med * 1e-3) / 1e9
+    res["layernorm"] = {"ms": med, "min_ms": mn, "GBs": gbs}
+    print(f"layernorm M{M} D{D}: {med:8.3f} ms  {gbs:8.1f} GB/s", flush=True)
+    img = torch.rand(a.batch, 3, 224, 224, device=dev)
+    Wp = (torch.randn(D, 3, 16, 16, device=dev) * 0.05).bfloat16()
+    bp = torch.randn(D, device=dev)
+    for dt in (torch.float32, torch.bfloat16):
+        xi = img.to(dt)
+        med, mn = timeit(lambda: ops.patch_embed(xi, Wp, bp, 16))
+        by = a.batch * 3 * 224 * 224 * xi.element_size() + a.batch * 196 * D * 2 + D * 768 * 2
+        res[f"patch_embed_{str(dt)[6:]}"] = {"ms": med, "GBs": by / (med * 1e-3) / 1e9}
+        print(f"patch_embed in={dt}: {med:8.3f} ms  algorithmic {by / (med * 1e-3) / 1e9:8.1f} GB/s", flush=True)
+    if a.out:
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

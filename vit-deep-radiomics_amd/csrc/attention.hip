@@ -1,0 +1,267 @@
+// Fused multi-head self-attention for gfx950, head dim 64:  out = softmax(q k^T / 8) v per (image, head)
+//
+// Replaces F.scaled_dot_product_attention inside nn.MultiheadAttention (reference
+// src/models_archs.py:130-135) and Attention.forward of the frozen ViTs called at
+// src/tfds_dense_descriptor.py:123.  No mask, no dropout (eval).
+//
+// One workgroup (4 waves) per (image, head[, q-block]).  K of the current key chunk is staged in
+// LDS by global_load_lds as [key][64] bf16 (128-B rows, 16-B chunks XOR-swizzled by (key>>1)&7);
+// V is staged TRANSPOSED as Vt[d][key] (row stride NT*64+8 bytes, odd multiple of 8 -> the 8-byte
+// fragment reads are bank-conflict free).  Each wave owns 32-query tiles and computes
+//     S^T = K . Q^T   (MFMA 32x32x16, key on the accumulator row, query on the lane)
+// so a whole softmax row lives in one lane pair (lane, lane^32): row max / sum are register
+// reductions plus one cross-half shuffle.  exp2((s - max) * 0.125*log2 e) in fp32, P rounded to
+// bf16 IN the accumulator registers and fed straight back as the B operand of
+//     O^T = V^T . P^T   (the accumulator-as-operand form; the V fragment is read in the same
+//                        permuted key order the accumulator registers hold)
+// so P never touches LDS.  seq <= 288 runs as one chunk (no rescale); longer sequences run an
+// online softmax over 128-key chunks with one query tile per wave.
+#include "vdr_dev.h"
+#include "vdr_kernels.h"
+
+namespace vdr {
+
+struct AttnK {
+  const bf16_t* qkv;
+  bf16_t* out;
+  int seq, heads;
+  int64_t ld_qkv, ld_out;
+  int qt_per_block;  // query tiles handled by one workgroup
+  int n_chunks;      // key chunks of NT*32 keys
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
+  constexpr int KEYS = NT * 32;
+  constexpr int VT_STRIDE = NT * 64 + 8;  // bytes per d-row of Vt
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                 // KEYS * 128 B
+  char* sVt = smem + KEYS * 128;   // 64 * VT_STRIDE B
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5;
+  const int l31 = lane & 31;
+  const int swz = (lane >> 1) & 7;
+
+  const int b = blockIdx.x / p.heads;
+  const int hd = blockIdx.x - b * p.heads;
+  const int HD = p.heads * 64;
+  const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
+
+  const int nqt = (p.seq + 31) >> 5;
+  const int qt_begin = blockIdx.y * p.qt_per_block;
+  const int qt_end = min(nqt, qt_begin + p.qt_per_block);
+  const float sc = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
+
+  // per-wave running state (multi-chunk mode: exactly one query tile per wave)
+  f32x16 o[2];
+  float m_run = -INFINITY, l_run = 0.0f;
+  bf16x8 qf[4];
+
+  auto load_q = [&](int qt) {
+    int q = qt * 32 + l31;
+    q = q < p.seq ? q : p.seq - 1;
+    const bf16_t* src = qb + (int64_t)q * p.ld_qkv + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
+    m_run = -INFINITY;
+    l_run = 0.0f;
+  };
+
+  auto stage = [&](int kc0) {
+    // K: KEYS rows of 128 B, 8 rows per wave-instruction
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int piece = wave * NT + q;  // 0 .. 4*NT-1, rows piece*8 .. +7
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int key = kc0 + r;
+      key = key < p.seq ? key : p.seq - 1;
+      glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
+    }
+    // V^T: item = (key pair, 8-wide d chunk); pack the pair into one dword per d
+    for (int it = tid; it < NT * 128; it += 256) {
+      const int dc = (it >> 3) & 7;
+      const int kp = (it & 7) | ((it >> 6) << 3);
+      const int key0 = kc0 + 2 * kp;
+      bf16x8 v0, v1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v0[e] = (bf16_t)0.0f;
+        v1[e] = (bf16_t)0.0f;
+      }
+      if (key0 < p.seq) v0 = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key0 * p.ld_qkv + dc * 8);
+      if (key0 + 1 < p.seq) v1 = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(key0 + 1) * p.ld_qkv + dc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bf16x2 pr;
+        pr[0] = v0[e];
+        pr[1] = v1[e];
+        *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  auto process = [&](int kc0, bool rescale) {
+    f32x16 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf =
+            *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * ks + hh) ^ swz) * 16));
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // mask keys >= seq (only tiles that straddle or lie beyond the end)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (kc0 + t * 32 + 32 > p.seq) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kc0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.seq) s[t][e] = -INFINITY;
+        }
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (rescale) {
+      const float alpha = fast_exp2((m_run - m_new) * sc);
+      l_run *= alpha;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[nd][e] *= alpha;
+    }
+    m_run = m_new;
+    const float mb = m_new * sc;
+    float lsum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
+          const bf16_t pb = (bf16_t)pv;
+          lsum += (float)pb;  // normalise by the sum of what is actually multiplied into O
+          pf[j] = pb;
+        }
+        const int koff = (t * 32 + s2 * 16 + 4 * hh) * 2;
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd) {
+          const char* vrow = sVt + (nd * 32 + l31) * VT_STRIDE + koff;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+          bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = lo[j];
+            vf[4 + j] = hi[j];
+          }
+          o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the exp/cvt of later key slices from being hoisted (VGPR cap)
+      }
+    }
+    l_run += lsum;
+  };
+
+  auto store = [&](int qt) {
+    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = qt * 32 + l31;
+    if (q < p.seq) {
+      bf16_t* dst = ob + (int64_t)q * p.ld_out;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
+        }
+    }
+  };
+
+  if (p.n_chunks == 1) {
+    stage(0);
+    for (int qt = qt_begin + wave; qt < qt_end; qt += 4) {
+      load_q(qt);
+      process(0, false);
+      store(qt);
+    }
+  } else {
+    const int qt = qt_begin + wave;
+    const bool valid = qt < qt_end;  // wave-uniform
+    load_q(valid ? qt : qt_begin);
+    for (int c = 0; c < p.n_chunks; ++c) {
+      if (c) __syncthreads();  // every wave is done reading the previous chunk
+      stage(c * KEYS);
+      if (valid) process(c * KEYS, c > 0);
+    }
+    if (valid) store(qt);
+  }
+}
+
+template <int NT>
+static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
+  constexpr size_t lds = (size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8);
+  auto fn = attn_kernel<NT>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int nqt = (k.seq + 31) / 32;
+  const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
+                            hipStream_t s) {
+  if (batch <= 0 || seq <= 0 || heads <= 0) return hipErrorInvalidValue;
+  AttnK k;
+  k.qkv = (const bf16_t*)qkv;
+  k.out = (bf16_t*)out;
+  k.seq = seq;
+  k.heads = heads;
+  k.ld_qkv = (int64_t)3 * heads * 64;
+  k.ld_out = (int64_t)heads * 64;
+  const int nqt = (seq + 31) / 32;
+  if (variant == 1 || seq > 288) {
+    // online softmax over 128-key chunks, one query tile per wave
+    k.qt_per_block = 4;
+    k.n_chunks = (seq + 127) / 128;
+    return launch_nt<4>(k, batch, s);
+  }
+  k.qt_per_block = nqt;
+  k.n_chunks = 1;
+  if (seq <= 64) return launch_nt<2>(k, batch, s);
+  if (seq <= 128) return launch_nt<4>(k, batch, s);
+  if (seq <= 224) return launch_nt<7>(k, batch, s);
+  return launch_nt<9>(k, batch, s);
+}
+
+}  // namespace vdr

@@ -1,0 +1,326 @@
+// HBM-bound row kernels for gfx950: LayerNorm (+ row gather / CLS extraction), im2col for the
+// patchify conv, CLS-row and token assembly.
+//
+// LayerNorm replaces nn.LayerNorm (reference src/models_archs.py:136,145; norm1/norm2/norm of the
+// ViT blocks): biased variance, fp32 statistics, eps configurable.  One 64-lane wave per row, the
+// whole row held in registers (4 elements per lane per pass), two-pass mean/variance with
+// wave-wide shuffle reductions — 2*D*sizeof bytes of HBM traffic per row and nothing else.
+// The row maps fold the x[:,0,:] CLS slice (models_archs.py:147) and the x[:,1:,:] dense slice
+// (tfds_dense_descriptor.py:130-133) into the final LayerNorm.
+#include "vdr_dev.h"
+#include "vdr_kernels.h"
+
+namespace vdr {
+
+struct LnK {
+  const void* x;
+  void* y;
+  const float* gamma;
+  const float* beta;
+  const float* cls;
+  int64_t rows;
+  int D;
+  float eps;
+  int irpg;
+  int64_t igs;
+  int ioff;
+  int orpg;
+  int64_t ogs;
+  int ooff;
+  int cls_period;
+};
+
+VDR_DEV int64_t map_row(int64_t r, int rpg, int64_t gs, int off) {
+  if (rpg >= (1 << 30)) return r;
+  const int64_t g = r / rpg;
+  return g * gs + off + (r - g * rpg);
+}
+
+template <bool IN_BF16, bool OUT_BF16, int NP>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnK p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const int64_t ir = map_row(r, p.irpg, p.igs, p.ioff);
+  const int64_t orow = map_row(r, p.orpg, p.ogs, p.ooff);
+  const bool from_cls = p.cls != nullptr && (r % p.cls_period) == 0;
+  float v[NP][4];
+  float sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < p.D) {
+      if (from_cls) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.cls + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = t[e];
+      } else if (IN_BF16) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16_t*)p.x + ir * p.D + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = (float)t[e];
+      } else {
+        const f32x4 t = *reinterpret_cast<const f32x4*>((const float*)p.x + ir * p.D + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = t[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += v[k][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[k][e] = 0.0f;
+    }
+  }
+  const float invD = 1.0f / (float)p.D;
+  const float mean = wave_sum(sum) * invD;
+  float sq = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < p.D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[k][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) * invD + p.eps);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < p.D) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * g[e] + bt[e];
+      if (OUT_BF16) {
+        bf16x4 ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ob[e] = (bf16_t)o[e];
+        *reinterpret_cast<bf16x4*>((bf16_t*)p.y + orow * p.D + c) = ob;
+      } else {
+        f32x4 of;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) of[e] = o[e];
+        *reinterpret_cast<f32x4*>((float*)p.y + orow * p.D + c) = of;
+      }
+    }
+  }
+}
+
+template <bool IB, bool OB>
+static hipError_t ln_dispatch(const LnK& k, hipStream_t s) {
+  const int np = (k.D + 255) / 256;
+  const dim3 grid((unsigned)((k.rows + 3) / 4)), block(256);
+#define VDR_LN(NP)                                                              \
+  case NP:                                                                      \
+    hipLaunchKernelGGL((layernorm_kernel<IB, OB, NP>), grid, block, 0, s, k);   \
+    break;
+  switch (np) {
+    VDR_LN(1) VDR_LN(2) VDR_LN(3) VDR_LN(4) VDR_LN(5) VDR_LN(6) VDR_LN(7) VDR_LN(8)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef VDR_LN
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
+  if (a.rows <= 0 || a.D <= 0 || (a.D & 3) || a.D > 2048) return hipErrorInvalidValue;
+  LnK k;
+  k.x = a.x;
+  k.y = a.y;
+  k.gamma = a.gamma;
+  k.beta = a.beta;
+  k.cls = a.cls;
+  k.rows = a.rows;
+  k.D = a.D;
+  k.eps = a.eps;
+  k.irpg = a.imap.rpg;
+  k.igs = a.imap.gstride;
+  k.ioff = a.imap.off;
+  k.orpg = a.omap.rpg;
+  k.ogs = a.omap.gstride;
+  k.ooff = a.omap.off;
+  k.cls_period = a.cls_period > 0 ? a.cls_period : 1;
+  if (a.in_bf16) return a.out_bf16 ? ln_dispatch<true, true>(k, s) : ln_dispatch<true, false>(k, s);
+  return a.out_bf16 ? ln_dispatch<false, true>(k, s) : ln_dispatch<false, false>(k, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col for Conv2d(C, D, kernel=p, stride=p): col[b*n + py*g + px][c*p*p + ky*p + kx]
+// One thread writes 8 consecutive k (one 16-byte store).
+// ---------------------------------------------------------------------------------------------
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ images, bf16_t* __restrict__ col,
+                                                     int64_t total8, int C, int img, int p, int g, int Kp, int fast) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total8) return;
+  const int k8 = Kp >> 3;
+  const int64_t row = idx / k8;
+  const int kk = (int)(idx - row * k8) * 8;
+  const int n = g * g;
+  const int64_t b = row / n;
+  const int pi = (int)(row - b * n);
+  const int py = pi / g, px = pi - py * g;
+  const int pp = p * p;
+  const int Kreal = C * pp;
+  bf16x8 o;
+  if (fast && kk < Kreal) {
+    const int c = kk / pp;
+    const int rem = kk - c * pp;
+    const int ky = rem / p, kx = rem - ky * p;
+    const int64_t src = ((b * C + c) * img + (py * p + ky)) * (int64_t)img + px * p + kx;
+    if (IN_BF16) {
+      o = *reinterpret_cast<const bf16x8*>((const bf16_t*)images + src);
+    } else {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>((const float*)images + src);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>((const float*)images + src + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (bf16_t)a0[e];
+        o[4 + e] = (bf16_t)a1[e];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kk + e;
+      float val = 0.0f;
+      if (k < Kreal) {
+        const int c = k / pp;
+        const int rem = k - c * pp;
+        const int ky = rem / p, kx = rem - ky * p;
+        const int64_t src = ((b * C + c) * img + (py * p + ky)) * (int64_t)img + px * p + kx;
+        val = IN_BF16 ? (float)((const bf16_t*)images)[src] : ((const float*)images)[src];
+      }
+      o[e] = (bf16_t)val;
+    }
+  }
+  *reinterpret_cast<bf16x8*>(col + row * Kp + kk) = o;
+}
+
+hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,
+                         int Kp, hipStream_t s) {
+  if (batch <= 0 || p <= 0 || img % p || (Kp & 63) || Kp < C * p * p) return hipErrorInvalidValue;
+  // the fast path reads 8 pixels with vector loads: needs p % 8 == 0 and img % 8 == 0 so that every
+  // 8-pixel run starts 16-byte aligned (the image base is assumed 16-byte aligned)
+  const int g = img / p;
+  const int fast = ((p & 7) == 0 && (img & 7) == 0 && (((uintptr_t)images) & 15) == 0) ? 1 : 0;
+  const int64_t total8 = (int64_t)batch * g * g * (Kp / 8);
+  const dim3 grid((unsigned)((total8 + 255) / 256)), block(256);
+  if (in_bf16)
+    hipLaunchKernelGGL((im2col_kernel<true>), grid, block, 0, s, images, (bf16_t*)col, total8, C, img, p, g, Kp, fast);
+  else
+    hipLaunchKernelGGL((im2col_kernel<false>), grid, block, 0, s, images, (bf16_t*)col, total8, C, img, p, g, Kp, fast);
+  return hipGetLastError();
+}
+
+// x[b*row_stride][:] = cls + pos[0]
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                       bf16_t* __restrict__ x, int batch, int64_t row_stride, int D) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)batch * D) return;
+  const int64_t b = idx / D;
+  const int d = (int)(idx - b * D);
+  const float v = cls[d] + (pos ? pos[d] : 0.0f);
+  x[b * row_stride * D + d] = (bf16_t)v;
+}
+
+hipError_t launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int64_t row_stride, int D,
+                           hipStream_t s) {
+  const int64_t total = (int64_t)batch * D;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cls, pos,
+                     (bf16_t*)x, batch, row_stride, D);
+  return hipGetLastError();
+}
+
+// token model: x[b*(S+c) + c + i] = tok[b*S + i] (+ pos[c+i]);  x[b*(S+c)] = cls (+ pos[0])
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void assemble_kernel(const void* __restrict__ tok, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, bf16_t* __restrict__ x,
+                                                       int batch, int seq, int D, int has_cls) {
+  const int N = seq + has_cls;
+  const int d4 = D >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)batch * N * d4) return;
+  const int64_t row = idx / d4;
+  const int d = (int)(idx - row * d4) * 4;
+  const int64_t b = row / N;
+  const int t = (int)(row - b * N);
+  float v[4];
+  if (has_cls && t == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = cls[d + e];
+  } else {
+    const int64_t src = (b * seq + (t - has_cls)) * (int64_t)D + d;
+    if (IN_BF16) {
+      const bf16x4 a = *reinterpret_cast<const bf16x4*>((const bf16_t*)tok + src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)a[e];
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>((const float*)tok + src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a[e];
+    }
+  }
+  if (pos) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += pos[(int64_t)t * D + d + e];
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+  *reinterpret_cast<bf16x4*>(x + row * D + d) = o;
+}
+
+hipError_t launch_assemble_tokens(const void* tok, int in_bf16, const float* cls, const float* pos, void* x,
+                                  int batch, int seq, int D, int has_cls, hipStream_t s) {
+  if (D & 3) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)batch * (seq + has_cls) * (D / 4);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (in_bf16)
+    hipLaunchKernelGGL((assemble_kernel<true>), grid, block, 0, s, tok, cls, pos, (bf16_t*)x, batch, seq, D, has_cls);
+  else
+    hipLaunchKernelGGL((assemble_kernel<false>), grid, block, 0, s, tok, cls, pos, (bf16_t*)x, batch, seq, D, has_cls);
+  return hipGetLastError();
+}
+
+// y[r][:] = x[imap(r)][:]  (bf16 in; bf16 or fp32 out) — the x[:,0,:] / x[:,1:,:] slice for models
+// without a final norm (post-LN nn.TransformerEncoder, models_archs.py:147)
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ x, void* __restrict__ y,
+                                                          int64_t rows, int D, int rpg, int64_t gs, int off) {
+  const int d4 = D >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * d4) return;
+  const int64_t r = idx / d4;
+  const int d = (int)(idx - r * d4) * 4;
+  const int64_t ir = map_row(r, rpg, gs, off);
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(x + ir * D + d);
+  if (OUT_BF16) {
+    *reinterpret_cast<bf16x4*>((bf16_t*)y + r * D + d) = a;
+  } else {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)a[e];
+    *reinterpret_cast<f32x4*>((float*)y + r * D + d) = o;
+  }
+}
+
+hipError_t launch_gather_rows(const void* x, void* y, int out_bf16, int64_t rows, int D, RowMap imap,
+                              hipStream_t s) {
+  if (D & 3) return hipErrorInvalidValue;
+  const int64_t total = rows * (D / 4);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (out_bf16)
+    hipLaunchKernelGGL((gather_rows_kernel<true>), grid, block, 0, s, (const bf16_t*)x, y, rows, D, imap.rpg,
+                       imap.gstride, imap.off);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<false>), grid, block, 0, s, (const bf16_t*)x, y, rows, D, imap.rpg,
+                       imap.gstride, imap.off);
+  return hipGetLastError();
+}
+
+}  // namespace vdr

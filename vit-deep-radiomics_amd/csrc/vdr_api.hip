@@ -1,0 +1,777 @@
+// C ABI of libvdr.so (include/vdr.h): handle, weight packing, forward orchestration, profiler.
+// Host code only; every kernel lives in gemm.hip / attention.hip / rowops.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/vdr.h"
+#include "vdr_kernels.h"
+
+using namespace vdr;
+
+namespace {
+
+thread_local std::string g_err;
+
+uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // keep NaN a NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                  // round to nearest even
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+enum WKind { W_VEC_F32, W_MAT_BF16, W_PATCH_BF16, W_W12_BF16, W_W12_BIAS };
+
+struct WSlot {
+  std::string name;
+  WKind kind;
+  int64_t numel;      // expected fp32 elements from the caller
+  int64_t rows, cols; // logical matrix shape for MAT kinds
+  void* dev = nullptr;
+  bool set = false;
+};
+
+struct LayerW {
+  const float *n1w, *n1b, *n2w, *n2b, *bqkv, *bproj, *b1, *b2, *ls1, *ls2;
+  const void *wqkv, *wproj, *w1, *w2;
+};
+
+struct ProfEvent {
+  int cls;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct vdr_model {
+  vdr_config cfg;
+  int device = 0;
+  int n_patches = 0, n_tokens = 0, Kp = 0;
+  std::vector<WSlot> slots;
+  std::map<std::string, int> index;
+  std::vector<LayerW> layers;
+  const void* w_patch = nullptr;
+  const float *b_patch = nullptr, *cls = nullptr, *pos = nullptr, *normw = nullptr, *normb = nullptr,
+              *inw = nullptr, *inb = nullptr;
+  bool resolved = false;
+  std::string err;
+  // profiler
+  bool prof = false;
+  std::vector<ProfEvent> ev_used, ev_free;
+  double p_flops[VDR_K_COUNT] = {0}, p_bytes[VDR_K_COUNT] = {0};
+  int64_t p_launch[VDR_K_COUNT] = {0};
+};
+
+namespace {
+
+int fail(vdr_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+
+int hip_fail(vdr_handle h, hipError_t e, const char* what) {
+  return fail(h, VDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+void add_slot(vdr_model* m, const std::string& name, WKind kind, int64_t rows, int64_t cols) {
+  WSlot s;
+  s.name = name;
+  s.kind = kind;
+  s.rows = rows;
+  s.cols = cols;
+  s.numel = rows * cols;
+  m->index[name] = (int)m->slots.size();
+  m->slots.push_back(s);
+}
+
+void build_slots(vdr_model* m) {
+  const vdr_config& c = m->cfg;
+  const int D = c.dim, F = c.mlp_hidden;
+  if (c.patch) {
+    add_slot(m, "patch_embed.proj.weight", W_PATCH_BF16, D, (int64_t)c.in_chans * c.patch * c.patch);
+    add_slot(m, "patch_embed.proj.bias", W_VEC_F32, 1, D);
+  }
+  if (c.has_cls) add_slot(m, "cls_token", W_VEC_F32, 1, D);
+  if (c.has_pos) add_slot(m, "pos_embed", W_VEC_F32, m->n_tokens, D);
+  if (c.input_ln) {
+    add_slot(m, "input_norm.weight", W_VEC_F32, 1, D);
+    add_slot(m, "input_norm.bias", W_VEC_F32, 1, D);
+  }
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    add_slot(m, p + "norm1.weight", W_VEC_F32, 1, D);
+    add_slot(m, p + "norm1.bias", W_VEC_F32, 1, D);
+    add_slot(m, p + "attn.qkv.weight", W_MAT_BF16, 3 * D, D);
+    add_slot(m, p + "attn.qkv.bias", W_VEC_F32, 1, 3 * D);
+    add_slot(m, p + "attn.proj.weight", W_MAT_BF16, D, D);
+    add_slot(m, p + "attn.proj.bias", W_VEC_F32, 1, D);
+    if (c.layerscale) add_slot(m, p + "ls1.gamma", W_VEC_F32, 1, D);
+    add_slot(m, p + "norm2.weight", W_VEC_F32, 1, D);
+    add_slot(m, p + "norm2.bias", W_VEC_F32, 1, D);
+    if (c.act == VDR_ACT_SWIGLU) {
+      add_slot(m, p + "mlp.w12.weight", W_W12_BF16, 2 * F, D);
+      add_slot(m, p + "mlp.w12.bias", W_W12_BIAS, 1, 2 * F);
+      add_slot(m, p + "mlp.w3.weight", W_MAT_BF16, D, F);
+      add_slot(m, p + "mlp.w3.bias", W_VEC_F32, 1, D);
+    } else {
+      add_slot(m, p + "mlp.fc1.weight", W_MAT_BF16, F, D);
+      add_slot(m, p + "mlp.fc1.bias", W_VEC_F32, 1, F);
+      add_slot(m, p + "mlp.fc2.weight", W_MAT_BF16, D, F);
+      add_slot(m, p + "mlp.fc2.bias", W_VEC_F32, 1, D);
+    }
+    if (c.layerscale) add_slot(m, p + "ls2.gamma", W_VEC_F32, 1, D);
+  }
+  if (c.pre_ln) {
+    add_slot(m, "norm.weight", W_VEC_F32, 1, D);
+    add_slot(m, "norm.bias", W_VEC_F32, 1, D);
+  }
+}
+
+const void* dev_of(vdr_model* m, const std::string& name) {
+  auto it = m->index.find(name);
+  return it == m->index.end() ? nullptr : m->slots[it->second].dev;
+}
+
+int resolve(vdr_model* m) {
+  for (auto& s : m->slots)
+    if (!s.set) return fail(m, VDR_ERR_INCOMPLETE, "weight not set: " + s.name);
+  const vdr_config& c = m->cfg;
+  m->w_patch = dev_of(m, "patch_embed.proj.weight");
+  m->b_patch = (const float*)dev_of(m, "patch_embed.proj.bias");
+  m->cls = (const float*)dev_of(m, "cls_token");
+  m->pos = (const float*)dev_of(m, "pos_embed");
+  m->inw = (const float*)dev_of(m, "input_norm.weight");
+  m->inb = (const float*)dev_of(m, "input_norm.bias");
+  m->normw = (const float*)dev_of(m, "norm.weight");
+  m->normb = (const float*)dev_of(m, "norm.bias");
+  m->layers.resize(c.layers);
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    LayerW& L = m->layers[i];
+    L.n1w = (const float*)dev_of(m, p + "norm1.weight");
+    L.n1b = (const float*)dev_of(m, p + "norm1.bias");
+    L.n2w = (const float*)dev_of(m, p + "norm2.weight");
+    L.n2b = (const float*)dev_of(m, p + "norm2.bias");
+    L.wqkv = dev_of(m, p + "attn.qkv.weight");
+    L.bqkv = (const float*)dev_of(m, p + "attn.qkv.bias");
+    L.wproj = dev_of(m, p + "attn.proj.weight");
+    L.bproj = (const float*)dev_of(m, p + "attn.proj.bias");
+    L.ls1 = (const float*)dev_of(m, p + "ls1.gamma");
+    L.ls2 = (const float*)dev_of(m, p + "ls2.gamma");
+    if (c.act == VDR_ACT_SWIGLU) {
+      L.w1 = dev_of(m, p + "mlp.w12.weight");
+      L.b1 = (const float*)dev_of(m, p + "mlp.w12.bias");
+      L.w2 = dev_of(m, p + "mlp.w3.weight");
+      L.b2 = (const float*)dev_of(m, p + "mlp.w3.bias");
+    } else {
+      L.w1 = dev_of(m, p + "mlp.fc1.weight");
+      L.b1 = (const float*)dev_of(m, p + "mlp.fc1.bias");
+      L.w2 = dev_of(m, p + "mlp.fc2.weight");
+      L.b2 = (const float*)dev_of(m, p + "mlp.fc2.bias");
+    }
+  }
+  m->resolved = true;
+  return VDR_OK;
+}
+
+// ---- workspace carving ------------------------------------------------------------------------
+struct Carve {
+  char *x, *h, *qkv, *o, *u;
+  size_t total;
+};
+
+Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
+  const vdr_config& c = m->cfg;
+  const size_t Mp = (size_t)round_up(mb * ntok, 256) + 256;
+  const size_t D = c.dim, F = c.mlp_hidden;
+  size_t off = 0;
+  Carve w;
+  auto take = [&](size_t bytes) {
+    char* p = base + off;
+    off += align256(bytes);
+    return p;
+  };
+  w.x = take(Mp * D * 2);
+  w.h = take(Mp * D * 2);
+  w.qkv = take(Mp * 3 * D * 2);
+  w.o = take(Mp * D * 2);
+  size_t ub = Mp * F * 2;
+  if (c.patch) {
+    const size_t colb = (size_t)mb * m->n_patches * m->Kp * 2 + 4096;
+    if (colb > ub) ub = colb;
+  }
+  w.u = take(ub);
+  w.total = off;
+  return w;
+}
+
+int default_micro_batch(const vdr_model* m, int batch) {
+  if (m->cfg.micro_batch > 0) return m->cfg.micro_batch < batch ? m->cfg.micro_batch : batch;
+  return batch;
+}
+
+// ---- profiler -----------------------------------------------------------------------------------
+struct Scope {
+  vdr_model* m;
+  hipStream_t s;
+  ProfEvent e;
+  bool on;
+  Scope(vdr_model* m_, hipStream_t s_, int cls, double flops, double bytes) : m(m_), s(s_), on(m_->prof) {
+    if (!on) return;
+    if (!m->ev_free.empty()) {
+      e = m->ev_free.back();
+      m->ev_free.pop_back();
+    } else {
+      hipEventCreate(&e.a);
+      hipEventCreate(&e.b);
+    }
+    e.cls = cls;
+    m->p_flops[cls] += flops;
+    m->p_bytes[cls] += bytes;
+    m->p_launch[cls] += 1;
+    hipEventRecord(e.a, s);
+  }
+  ~Scope() {
+    if (!on) return;
+    hipEventRecord(e.b, s);
+    m->ev_used.push_back(e);
+  }
+};
+
+#define VDR_TRY(expr, what)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return hip_fail(m, _e, what); \
+  } while (0)
+
+int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
+         const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi) {
+  GemmArgs g{};
+  g.A = A;
+  g.W = W;
+  g.bias = bias;
+  g.resid = resid;
+  g.gamma = gamma;
+  g.C = C;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldw = K;
+  g.ldc = ldc;
+  g.ldr = ldc;
+  g.omap = identity_map();
+  const double outw = epi == EPI_SWIGLU ? N / 2 : N;
+  Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
+  VDR_TRY(launch_gemm(g, epi, 0, s), "gemm");
+  return VDR_OK;
+}
+
+int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, void* y, int out_bf16,
+              const float* gw, const float* gb, int64_t rows, RowMap imap, const float* clsrc = nullptr,
+              int cls_period = 0) {
+  LnArgs a{};
+  a.x = x;
+  a.in_bf16 = in_bf16;
+  a.y = y;
+  a.out_bf16 = out_bf16;
+  a.gamma = gw;
+  a.beta = gb;
+  a.rows = rows;
+  a.D = m->cfg.dim;
+  a.eps = m->cfg.ln_eps;
+  a.imap = imap;
+  a.omap = identity_map();
+  a.cls = clsrc;
+  a.cls_period = cls_period;
+  Scope sc(m, s, cls, 0.0, (double)rows * a.D * ((in_bf16 ? 2 : 4) + (out_bf16 ? 2 : 4)));
+  VDR_TRY(launch_layernorm(a, s), "layernorm");
+  return VDR_OK;
+}
+
+// L transformer blocks over x [M = mb*ntok rows]; leaves the result in w.x
+int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
+  const vdr_config& c = m->cfg;
+  const int D = c.dim, F = c.mlp_hidden, H = c.heads;
+  const int64_t M = (int64_t)mb * ntok;
+  const bool sw = c.act == VDR_ACT_SWIGLU;
+  int rc;
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& L = m->layers[i];
+    const void* attn_in = w.x;
+    if (c.pre_ln) {
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
+      attn_in = w.h;
+    }
+    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS)))
+      return rc;
+    {
+      Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
+      VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, 0, s), "attention");
+    }
+    if (c.pre_ln) {
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.h, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+        return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
+    } else {
+      // nn.TransformerEncoderLayer, norm_first=False: x = LN1(x + SA(x)); x = LN2(x + FF(x))
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.h, M, D, D, D, EPI_BIAS_RESID))) return rc;
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.h, 1, w.x, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+        return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.h, M, D, F, D, EPI_BIAS_RESID))) return rc;
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.h, 1, w.x, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
+    }
+  }
+  return VDR_OK;
+}
+
+// slice (and final-normalise) the token buffer into the caller's output
+int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_mode, int out_dtype, char* out) {
+  const vdr_config& c = m->cfg;
+  const int D = c.dim;
+  RowMap im;
+  int64_t rows;
+  const int ncls = c.has_cls ? 1 : 0;
+  if (out_mode == VDR_OUT_CLS) {
+    im = RowMap{1, ntok, 0};
+    rows = mb;
+  } else if (out_mode == VDR_OUT_DENSE) {
+    im = RowMap{ntok - ncls, ntok, ncls};
+    rows = (int64_t)mb * (ntok - ncls);
+  } else {
+    im = identity_map();
+    rows = (int64_t)mb * ntok;
+  }
+  const int ob = out_dtype == VDR_BF16;
+  if (c.pre_ln) return layernorm(m, s, VDR_K_FINAL_LN, w.x, 1, out, ob, m->normw, m->normb, rows, im);
+  Scope sc(m, s, VDR_K_FINAL_LN, 0.0, (double)rows * D * (2 + (ob ? 2 : 4)));
+  VDR_TRY(launch_gather_rows(w.x, out, ob, rows, D, im, s), "gather_rows");
+  return VDR_OK;
+}
+
+size_t out_row_bytes(const vdr_model* m, int out_dtype) { return (size_t)m->cfg.dim * (out_dtype == VDR_BF16 ? 2 : 4); }
+
+int check_device(vdr_handle h) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(h, VDR_ERR_NO_DEVICE, "no HIP device visible: libvdr has no CPU path");
+  }
+  return VDR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int vdr_abi_version(void) { return VDR_ABI_VERSION; }
+
+int vdr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* vdr_last_error(vdr_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+const char* vdr_kernel_class_name(int k) {
+  static const char* names[VDR_K_COUNT] = {"im2col",   "gemm_patch", "layernorm", "gemm_qkv", "attention",
+                                           "gemm_proj", "gemm_fc1",  "gemm_fc2",  "final_ln", "assemble"};
+  return (k >= 0 && k < VDR_K_COUNT) ? names[k] : "?";
+}
+
+int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
+  if (!cfg || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  const vdr_config& c = *cfg;
+  if (c.dim <= 0 || c.heads <= 0 || c.layers < 0 || c.mlp_hidden <= 0)
+    return fail(nullptr, VDR_ERR_INVALID, "dim/heads/layers/mlp_hidden must be positive");
+  if (c.dim != c.heads * 64) return fail(nullptr, VDR_ERR_UNSUPPORTED, "head dim must be 64 (dim == 64*heads)");
+  if (c.dim % 64 || c.mlp_hidden % 64 || c.dim > 2048)
+    return fail(nullptr, VDR_ERR_UNSUPPORTED, "dim and mlp_hidden must be multiples of 64, dim <= 2048");
+  if (c.patch) {
+    if (c.img <= 0 || c.img % c.patch || c.in_chans <= 0) return fail(nullptr, VDR_ERR_INVALID, "img must be a multiple of patch");
+  } else if (c.has_pos) {
+    return fail(nullptr, VDR_ERR_UNSUPPORTED, "token models carry no learned pos_embed");
+  }
+  if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  int ndev = 0;
+  hipGetDeviceCount(&ndev);
+  if (device < 0 || device >= ndev) return fail(nullptr, VDR_ERR_INVALID, "device index out of range");
+  std::unique_ptr<vdr_model> m(new vdr_model());
+  m->cfg = c;
+  m->device = device;
+  if (c.patch) {
+    const int g = c.img / c.patch;
+    m->n_patches = g * g;
+    m->n_tokens = m->n_patches + (c.has_cls ? 1 : 0);
+    m->Kp = round_up(c.in_chans * c.patch * c.patch, 64);
+  }
+  build_slots(m.get());
+  *out = m.release();
+  return VDR_OK;
+}
+
+void vdr_destroy(vdr_handle h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  for (auto& s : h->slots)
+    if (s.dev) hipFree(s.dev);
+  for (auto& e : h->ev_used) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  for (auto& e : h->ev_free) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  delete h;
+}
+
+int vdr_num_weights(vdr_handle h) { return h ? (int)h->slots.size() : 0; }
+
+const char* vdr_weight_name(vdr_handle h, int i) {
+  if (!h || i < 0 || i >= (int)h->slots.size()) return nullptr;
+  return h->slots[i].name.c_str();
+}
+
+int vdr_set_weight(vdr_handle m, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!m || !name || !host || (ndim > 0 && !shape)) return fail(m, VDR_ERR_INVALID, "null argument");
+  auto it = m->index.find(name);
+  if (it == m->index.end()) return fail(m, VDR_ERR_UNKNOWN_NAME, std::string("unknown weight name: ") + name);
+  WSlot& s = m->slots[it->second];
+  int64_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= shape[i];
+  if (numel != s.numel)
+    return fail(m, VDR_ERR_INVALID, std::string(name) + ": expected " + std::to_string(s.numel) + " elements, got " +
+                                        std::to_string(numel));
+  VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+  std::vector<uint16_t> bf;
+  std::vector<float> fv;
+  const void* src = host;
+  size_t bytes = 0;
+  const int F = m->cfg.mlp_hidden;
+  switch (s.kind) {
+    case W_VEC_F32:
+      bytes = (size_t)numel * 4;
+      break;
+    case W_MAT_BF16:
+      bf.resize(numel);
+      for (int64_t i = 0; i < numel; ++i) bf[i] = f32_to_bf16(host[i]);
+      src = bf.data();
+      bytes = (size_t)numel * 2;
+      break;
+    case W_PATCH_BF16: {
+      // [D, C*p*p] -> [D, Kp] zero padded along k
+      const int64_t K = s.cols, Kp = m->Kp;
+      bf.assign((size_t)s.rows * Kp, 0);
+      for (int64_t r = 0; r < s.rows; ++r)
+        for (int64_t k = 0; k < K; ++k) bf[r * Kp + k] = f32_to_bf16(host[r * K + k]);
+      src = bf.data();
+      bytes = bf.size() * 2;
+      break;
+    }
+    case W_W12_BF16: {
+      // SwiGLU: interleave x1/x2 rows in blocks of 32 so one wave tile holds a gate pair:
+      // packed row 64*blk + t = (t < 32 ? x1[32*blk + t] : x2[32*blk + t - 32])
+      if (F % 32) return fail(m, VDR_ERR_UNSUPPORTED, "SwiGLU hidden must be a multiple of 32");
+      const int64_t K = s.cols;
+      bf.resize(numel);
+      for (int64_t pr = 0; pr < 2 * F; ++pr) {
+        const int64_t blk = pr / 64, t = pr % 64;
+        const int64_t srow = t < 32 ? blk * 32 + t : F + blk * 32 + (t - 32);
+        for (int64_t k = 0; k < K; ++k) bf[pr * K + k] = f32_to_bf16(host[srow * K + k]);
+      }
+      src = bf.data();
+      bytes = (size_t)numel * 2;
+      break;
+    }
+    case W_W12_BIAS: {
+      fv.resize(numel);
+      for (int64_t pr = 0; pr < 2 * F; ++pr) {
+        const int64_t blk = pr / 64, t = pr % 64;
+        fv[pr] = host[t < 32 ? blk * 32 + t : F + blk * 32 + (t - 32)];
+      }
+      src = fv.data();
+      bytes = (size_t)numel * 4;
+      break;
+    }
+  }
+  if (!s.dev) VDR_TRY(hipMalloc(&s.dev, bytes + 256), "hipMalloc(weight)");
+  VDR_TRY(hipMemcpy(s.dev, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(weight)");
+  s.set = true;
+  m->resolved = false;
+  return VDR_OK;
+}
+
+int vdr_workspace_bytes(vdr_handle m, int batch, int seq, size_t* out) {
+  if (!m || !out || batch <= 0) return fail(m, VDR_ERR_INVALID, "bad argument");
+  const int ntok = m->cfg.patch ? m->n_tokens : seq + (m->cfg.has_cls ? 1 : 0);
+  if (ntok <= 0) return fail(m, VDR_ERR_INVALID, "seq must be positive for a token model");
+  const int mb = default_micro_batch(m, batch);
+  *out = carve(m, nullptr, mb, ntok).total;
+  return VDR_OK;
+}
+
+int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void* out, int out_mode, int out_dtype,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !images || !out || !workspace || batch <= 0) return fail(m, VDR_ERR_INVALID, "null/invalid argument");
+  const vdr_config& c = m->cfg;
+  if (!c.patch) return fail(m, VDR_ERR_INVALID, "vdr_forward needs an image model (patch > 0)");
+  if (in_dtype != VDR_F32 && in_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "in_dtype");
+  if (out_dtype != VDR_F32 && out_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "out_dtype");
+  if (out_mode < VDR_OUT_CLS || out_mode > VDR_OUT_TOKENS) return fail(m, VDR_ERR_INVALID, "out_mode");
+  if (out_mode == VDR_OUT_CLS && !c.has_cls) return fail(m, VDR_ERR_INVALID, "model has no cls token");
+  int rc = check_device(m);
+  if (rc) return rc;
+  if (!m->resolved && (rc = resolve(m))) return rc;
+  const int mb_max = default_micro_batch(m, batch);
+  const int ntok = m->n_tokens, n = m->n_patches, D = c.dim;
+  const Carve w = carve(m, (char*)workspace, mb_max, ntok);
+  if (w.total > workspace_bytes)
+    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t img_elems = (size_t)c.in_chans * c.img * c.img;
+  const size_t in_es = in_dtype == VDR_BF16 ? 2 : 4;
+  const int ncls = c.has_cls ? 1 : 0;
+  for (int b0 = 0; b0 < batch; b0 += mb_max) {
+    const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
+    const char* img = (const char*)images + (size_t)b0 * img_elems * in_es;
+    {
+      Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)mb * img_elems * in_es + 2.0 * mb * n * m->Kp);
+      VDR_TRY(launch_im2col(img, in_dtype == VDR_BF16, w.u, mb, c.in_chans, c.img, c.patch, m->Kp, s), "im2col");
+    }
+    const bool pe_only = out_mode == VDR_OUT_PATCH_EMBED;
+    {
+      GemmArgs g{};
+      g.A = w.u;
+      g.W = m->w_patch;
+      g.bias = m->b_patch;
+      g.pos = pe_only ? nullptr : m->pos;
+      g.M = (int64_t)mb * n;
+      g.N = D;
+      g.K = m->Kp;
+      g.lda = m->Kp;
+      g.ldw = m->Kp;
+      g.ldc = D;
+      g.ldr = D;
+      if (pe_only && out_dtype == VDR_BF16) {
+        g.C = (char*)out + (size_t)b0 * n * D * 2;
+        g.omap = RowMap{n, n, 0};
+      } else if (pe_only) {
+        g.C = w.x;
+        g.omap = RowMap{n, n, 0};
+      } else {
+        g.C = w.x;
+        g.omap = RowMap{n, ntok, ncls};
+      }
+      Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
+               2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
+      VDR_TRY(launch_gemm(g, EPI_PATCH, 0, s), "patch gemm");
+    }
+    if (pe_only) {
+      if (out_dtype != VDR_BF16) {
+        Scope sc(m, s, VDR_K_FINAL_LN, 0.0, (double)mb * n * D * 6);
+        VDR_TRY(launch_gather_rows(w.x, (char*)out + (size_t)b0 * n * D * 4, 0, (int64_t)mb * n, D, identity_map(), s),
+                "gather_rows");
+      }
+      continue;
+    }
+    if (c.has_cls) {
+      Scope sc(m, s, VDR_K_ASSEMBLE, 0.0, (double)mb * D * 2);
+      VDR_TRY(launch_cls_rows(m->cls, m->pos, w.x, mb, ntok, D, s), "cls rows");
+    }
+    if (c.input_ln) {
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.x, 1, m->inw, m->inb, (int64_t)mb * ntok, identity_map())))
+        return rc;
+    }
+    if ((rc = run_blocks(m, s, w, mb, ntok))) return rc;
+    const int64_t rows_per_img = out_mode == VDR_OUT_CLS ? 1 : (out_mode == VDR_OUT_DENSE ? ntok - ncls : ntok);
+    char* o = (char*)out + (size_t)b0 * rows_per_img * out_row_bytes(m, out_dtype);
+    if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;
+  }
+  return VDR_OK;
+}
+
+int vdr_forward_tokens(vdr_handle m, const void* tokens, int in_dtype, int batch, int seq, void* out, int out_mode,
+                       int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!m || !tokens || !out || !workspace || batch <= 0 || seq <= 0) return fail(m, VDR_ERR_INVALID, "null/invalid argument");
+  const vdr_config& c = m->cfg;
+  if (c.patch) return fail(m, VDR_ERR_INVALID, "vdr_forward_tokens needs a token model (patch == 0)");
+  if (in_dtype != VDR_F32 && in_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "in_dtype");
+  if (out_dtype != VDR_F32 && out_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "out_dtype");
+  if (out_mode != VDR_OUT_CLS && out_mode != VDR_OUT_TOKENS && out_mode != VDR_OUT_DENSE)
+    return fail(m, VDR_ERR_INVALID, "out_mode");
+  if (out_mode == VDR_OUT_CLS && !c.has_cls) return fail(m, VDR_ERR_INVALID, "model has no cls token");
+  int rc = check_device(m);
+  if (rc) return rc;
+  if (!m->resolved && (rc = resolve(m))) return rc;
+  const int ncls = c.has_cls ? 1 : 0;
+  const int ntok = seq + ncls, D = c.dim;
+  const int mb_max = default_micro_batch(m, batch);
+  const Carve w = carve(m, (char*)workspace, mb_max, ntok);
+  if (w.total > workspace_bytes)
+    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t in_es = in_dtype == VDR_BF16 ? 2 : 4;
+  for (int b0 = 0; b0 < batch; b0 += mb_max) {
+    const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
+    const char* tok = (const char*)tokens + (size_t)b0 * seq * D * in_es;
+    const int64_t M = (int64_t)mb * ntok;
+    if (c.input_ln) {
+      // LayerNorm([cls ; tokens]) straight from the caller's buffer (models_archs.py:143-145)
+      const RowMap im = c.has_cls ? RowMap{ntok, seq, -1} : identity_map();
+      if ((rc = layernorm(m, s, VDR_K_ASSEMBLE, tok, in_dtype == VDR_BF16, w.x, 1, m->inw, m->inb, M, im,
+                          c.has_cls ? m->cls : nullptr, ntok)))
+        return rc;
+    } else {
+      Scope sc(m, s, VDR_K_ASSEMBLE, 0.0, (double)M * D * (in_es + 2));
+      VDR_TRY(launch_assemble_tokens(tok, in_dtype == VDR_BF16, m->cls, nullptr, w.x, mb, seq, D, ncls, s), "assemble");
+    }
+    if ((rc = run_blocks(m, s, w, mb, ntok))) return rc;
+    const int64_t rows_per = out_mode == VDR_OUT_CLS ? 1 : (out_mode == VDR_OUT_DENSE ? seq : ntok);
+    char* o = (char*)out + (size_t)b0 * rows_per * out_row_bytes(m, out_dtype);
+    if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;
+  }
+  return VDR_OK;
+}
+
+// ---- single operators -----------------------------------------------------------------------------
+#define OP_TRY(expr, what)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) return fail(nullptr, VDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const float* gamma, const float* beta,
+                     int64_t rows, int D, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  LnArgs a{};
+  a.x = x;
+  a.in_bf16 = in_dtype == VDR_BF16;
+  a.y = y;
+  a.out_bf16 = out_dtype == VDR_BF16;
+  a.gamma = gamma;
+  a.beta = beta;
+  a.rows = rows;
+  a.D = D;
+  a.eps = eps;
+  a.imap = identity_map();
+  a.omap = identity_map();
+  OP_TRY(launch_layernorm(a, (hipStream_t)stream), "layernorm");
+  return VDR_OK;
+}
+
+int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid, const float* gamma, void* y,
+                  int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+  if (!x || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (epilogue < VDR_EPI_BIAS || epilogue > VDR_EPI_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "epilogue");
+  if (epilogue == VDR_EPI_BIAS_RESID && !resid) return fail(nullptr, VDR_ERR_INVALID, "resid required");
+  if (K % 64 || N % 8) return fail(nullptr, VDR_ERR_UNSUPPORTED, "K % 64 == 0 and N % 8 == 0 required");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  GemmArgs g{};
+  g.A = x;
+  g.W = W;
+  g.bias = bias;
+  g.resid = resid;
+  g.gamma = gamma;
+  g.C = y;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldw = K;
+  g.ldc = epilogue == VDR_EPI_SWIGLU ? N / 2 : N;
+  g.ldr = g.ldc;
+  g.omap = identity_map();
+  OP_TRY(launch_gemm(g, epilogue, variant, (hipStream_t)stream), "gemm");
+  return VDR_OK;
+}
+
+int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant, void* stream) {
+  if (!qkv || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_attention(qkv, out, batch, seq, heads, variant, (hipStream_t)stream), "attention");
+  return VDR_OK;
+}
+
+int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const float* bias, const float* pos, void* col,
+                       void* y, int batch, int C, int img, int p, int D, int row_stride, int row_offset, void* stream) {
+  if (!images || !W || !col || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (p <= 0 || img % p) return fail(nullptr, VDR_ERR_INVALID, "img must be a multiple of p");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  const int g = img / p, n = g * g, Kp = round_up(C * p * p, 64);
+  OP_TRY(launch_im2col(images, in_dtype == VDR_BF16, col, batch, C, img, p, Kp, (hipStream_t)stream), "im2col");
+  GemmArgs a{};
+  a.A = col;
+  a.W = W;
+  a.bias = bias;
+  a.pos = pos;
+  a.C = y;
+  a.M = (int64_t)batch * n;
+  a.N = D;
+  a.K = Kp;
+  a.lda = Kp;
+  a.ldw = Kp;
+  a.ldc = D;
+  a.ldr = D;
+  a.omap = RowMap{n, row_stride, row_offset};
+  OP_TRY(launch_gemm(a, EPI_PATCH, 0, (hipStream_t)stream), "patch gemm");
+  return VDR_OK;
+}
+
+// ---- profiler ---------------------------------------------------------------------------------------
+int vdr_profile_enable(vdr_handle m, int on) {
+  if (!m) return fail(m, VDR_ERR_INVALID, "null handle");
+  m->prof = on != 0;
+  return VDR_OK;
+}
+
+int vdr_profile_read(vdr_handle m, double* ms, int64_t* launches, double* flops, double* bytes, int n) {
+  if (!m || !ms || n < VDR_K_COUNT) return fail(m, VDR_ERR_INVALID, "bad argument");
+  for (int k = 0; k < VDR_K_COUNT; ++k) ms[k] = 0.0;
+  for (auto& e : m->ev_used) {
+    VDR_TRY(hipEventSynchronize(e.b), "hipEventSynchronize");
+    float t = 0.0f;
+    VDR_TRY(hipEventElapsedTime(&t, e.a, e.b), "hipEventElapsedTime");
+    ms[e.cls] += t;
+    m->ev_free.push_back(e);
+  }
+  m->ev_used.clear();
+  for (int k = 0; k < VDR_K_COUNT; ++k) {
+    if (launches) launches[k] = m->p_launch[k];
+    if (flops) flops[k] = m->p_flops[k];
+    if (bytes) bytes[k] = m->p_bytes[k];
+    m->p_launch[k] = 0;
+    m->p_flops[k] = 0;
+    m->p_bytes[k] = 0;
+  }
+  return VDR_OK;
+}
+
+}  // extern "C"

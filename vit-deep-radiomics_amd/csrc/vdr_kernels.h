@@ -1,0 +1,72 @@
+// Host-side launch interface of the gfx950 kernels (internal; the public ABI is include/vdr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vdr {
+
+// row r of a compact [R, *] view  <->  row (r / rpg) * gstride + off + (r % rpg) of a token buffer
+struct RowMap {
+  int rpg;
+  int64_t gstride;
+  int off;
+};
+static inline RowMap identity_map() { return RowMap{1 << 30, 0, 0}; }
+
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_SWIGLU = 3, EPI_PATCH = 4 };
+
+struct GemmArgs {
+  const void* A;      // [M, K] bf16, row stride lda
+  const void* W;      // [N, K] bf16 (PyTorch Linear layout), row stride ldw
+  const float* bias;  // [N] or null
+  const void* resid;  // [*, ldr] bf16 (EPI_BIAS_RESID), indexed by the OUTPUT row
+  const float* gamma; // [N] LayerScale or null
+  const float* pos;   // [tokens, N] fp32 (EPI_PATCH), indexed by off + r % rpg
+  void* C;            // bf16, row stride ldc
+  int64_t M;
+  int N, K;
+  int64_t lda, ldw, ldc, ldr;
+  RowMap omap;        // output row map (EPI_PATCH); identity otherwise
+};
+
+hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
+int gemm_num_variants();
+
+// y[r] = LN(x[imap(r)]) ; optional cls source: rows with r % cls_period == 0 read cls (fp32 [D])
+struct LnArgs {
+  const void* x;
+  int in_bf16;
+  void* y;
+  int out_bf16;
+  const float* gamma;
+  const float* beta;
+  int64_t rows;  // output rows
+  int D;
+  float eps;
+  RowMap imap;
+  RowMap omap;
+  const float* cls;  // or null
+  int cls_period;
+};
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
+
+hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
+                            hipStream_t s);
+
+// images NCHW -> col [batch*n, Kp] bf16 with k = c*p*p + ky*p + kx, zero padded to Kp
+hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,
+                         int Kp, hipStream_t s);
+
+// x[b*row_stride + 0][:] = cls + pos[0]  (bf16 out)
+hipError_t launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int64_t row_stride,
+                           int D, hipStream_t s);
+
+// token assembly for the token model: x[b*(S+1)+1+i] = tok[b*S+i] (+pos), x[b*(S+1)] = cls (+pos[0]); bf16 out
+hipError_t launch_assemble_tokens(const void* tok, int in_bf16, const float* cls, const float* pos,
+                                  void* x, int batch, int seq, int D, int has_cls, hipStream_t s);
+
+// y[r] = x[imap(r)], bf16 -> bf16 / fp32
+hipError_t launch_gather_rows(const void* x, void* y, int out_bf16, int64_t rows, int D, RowMap imap,
+                              hipStream_t s);
+
+}  // namespace vdr

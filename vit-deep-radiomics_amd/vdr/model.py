@@ -1,0 +1,154 @@
+"""Host-side mirror of the reference's call boundary for the hot path.
+
+    R1  load_model(model_name, model_path)              src/tfds_dense_descriptor.py:51-67
+    R2  model.image_encoder(x) / model.patch_embed(x)   src/tfds_dense_descriptor.py:122-129
+        get_dense_descriptor(model, img) -> (h, w, D)   src/tfds_dense_descriptor.py:110-139
+    R3  model(x[B,S,D]) -> (logits[B,C], cls[B,D])      src/models_archs.py:141-147
+
+Same names, argument meaning and error behaviour (Python exceptions); everything below these
+methods runs in libvdr.so on the MI355X.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import Engine, VdrConfig
+
+# geometries BASELINE.json names + the two the reference itself loads
+ARCHS = {
+    "vit_tiny16_224": VdrConfig(224, 16, 3, 192, 3, 12, 768),
+    "vit_base16_224": VdrConfig(224, 16, 3, 768, 12, 12, 3072),
+    "vit_large14_336": VdrConfig(336, 14, 3, 1024, 16, 24, 4096),
+    "dinov2_giant14_224": VdrConfig(224, 14, 3, 1536, 24, 40, 4096, act="swiglu", layerscale=True),
+    # reference default for model_name='dinov2' (load_dinov2('small'), run at 896x896)
+    "dinov2": VdrConfig(896, 14, 3, 384, 6, 12, 1536, layerscale=True),
+}
+
+
+class VitDescriptorModel:
+    """Frozen-ViT feature extractor with the attributes the reference's hot loop dispatches on."""
+
+    def __init__(self, cfg: VdrConfig, weights: "dict[str, torch.Tensor]", model_name: str = "vit", device=None):
+        self.cfg = cfg
+        self.model_name = model_name  # tfds_dense_descriptor.py:66 assigns this attribute
+        self.engine = Engine(cfg, device)
+        self.engine.load_weights(weights)
+        self.device = self.engine.device
+
+    # -- nn.Module-style no-ops so reference code such as model.eval().cuda() keeps working
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # -- R2 -------------------------------------------------------------------------------------
+    def patch_embed(self, x: torch.Tensor) -> torch.Tensor:
+        """DINOv2 PatchEmbed: [B,3,H,W] -> [B,n,D] (tfds_dense_descriptor.py:128)."""
+        return self.engine.forward(x, L.OUT_PATCH_EMBED, torch.float32)
+
+    def image_encoder(self, x: torch.Tensor) -> torch.Tensor:
+        """Channel-first dense map [B,D,h,w], the layout tfds_dense_descriptor.py:123-126 squeezes and
+        transposes to (h,w,D)."""
+        B = x.shape[0]
+        g = self.cfg.img // self.cfg.patch
+        dense = self.engine.forward(x, L.OUT_DENSE, torch.float32)
+        return dense.reshape(B, g, g, self.cfg.dim).permute(0, 3, 1, 2)
+
+    def forward_features(self, x: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+        """[B,3,H,W] -> CLS features [B,D] (the [N,D] matrix embedding_classifier.py consumes)."""
+        return self.engine.forward(x, L.OUT_CLS, out_dtype)
+
+    def dense_tokens(self, x: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
+        return self.engine.forward(x, L.OUT_DENSE, out_dtype)
+
+    def __call__(self, x):
+        return self.forward_features(x)
+
+
+def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0):
+    """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
+    model_path: a PyTorch state_dict file with the canonical key names; loaded with
+    torch.load(weights_only=True).  weights: the same dict passed directly."""
+    if model_name == "medsam":
+        raise NotImplementedError("the SAM ViT-B@1024 windowed-attention encoder is SURVEY.md §8 row f-1 (next)")
+    if model_name not in ARCHS:
+        raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
+    cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch})
+    if weights is None:
+        if model_path is None:
+            raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
+        weights = torch.load(model_path, map_location="cpu", weights_only=True)
+    model = VitDescriptorModel(cfg, weights, model_name, device)
+    model.model_name = model_name
+    return model
+
+
+def get_dense_descriptor(model, img) -> np.ndarray:
+    """R2 wrapper with the reference's single-image contract: img (3,H,W) or (1,3,H,W) array/tensor,
+    already resized to the model's input side, values in [0,1]  ->  (h, w, D) float32 numpy.
+    (The skimage resize of prepare_image stays upstream: SURVEY.md §8 row f-3.)"""
+    t = torch.as_tensor(img, dtype=torch.float32)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    t = t.to(model.device)
+    if model.model_name == "medsam":
+        f = model.image_encoder(t).cpu().numpy()
+        return np.transpose(np.squeeze(f), (1, 2, 0))
+    f = np.squeeze(model.patch_embed(t).cpu().numpy())
+    s = int(np.sqrt(f.shape[0]))
+    return f.reshape(s, s, f.shape[1])
+
+
+def extract_dense(model, images: torch.Tensor, encoder: bool = True) -> np.ndarray:
+    """Batched counterpart of the reference's per-slice loop (tfds_dense_descriptor.py:271-281):
+    [B,3,H,W] -> (B, h, w, D) float32 numpy in one call."""
+    g = model.cfg.img // model.cfg.patch
+    f = model.engine.forward(images, L.OUT_DENSE if encoder else L.OUT_PATCH_EMBED, torch.float32)
+    return f.reshape(images.shape[0], g, g, model.cfg.dim).cpu().numpy()
+
+
+class TransformerNoduleClassifier:
+    """R3: drop-in for models_archs.TransformerNoduleClassifier in eval mode.
+    model(x[B,S,D]) -> (logits [B,C], cls [B,D])."""
+
+    def __init__(self, input_dim, dim_feedforward, num_heads, num_classes, num_layers, state_dict, device=None):
+        from .weights import from_torch_encoder_state_dict
+        cfg = VdrConfig(img=0, patch=0, in_chans=0, dim=input_dim, heads=num_heads, layers=num_layers,
+                        mlp_hidden=dim_feedforward, act="gelu", pre_ln=False, layerscale=False, has_cls=True,
+                        has_pos=False, input_ln=True, ln_eps=1e-5)
+        self.cfg = cfg
+        self.engine = Engine(cfg, device)
+        self.engine.load_weights(from_torch_encoder_state_dict(state_dict, num_layers))
+        dev = self.engine.device
+        sd = state_dict
+        self.num_classes = num_classes
+        # MLPLayer head (models_archs.py:186-200): dense1 -> GELU -> dense2, through vdr_op_linear;
+        # dense2's num_classes rows are zero-padded to 8 for the GEMM's N % 8 == 0 rule.
+        self.w1 = sd["classifier.dense1.weight"].to(dev, torch.bfloat16).contiguous()
+        self.b1 = sd["classifier.dense1.bias"].to(dev, torch.float32).contiguous()
+        npad = (num_classes + 7) // 8 * 8
+        w2 = torch.zeros((npad, self.w1.shape[0]), dtype=torch.float32)
+        w2[:num_classes] = sd["classifier.dense2.weight"].float().cpu()
+        b2 = torch.zeros((npad,), dtype=torch.float32)
+        b2[:num_classes] = sd["classifier.dense2.bias"].float().cpu()
+        self.w2 = w2.to(dev, torch.bfloat16).contiguous()
+        self.b2 = b2.to(dev)
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, x: torch.Tensor):
+        from . import ops
+        cls = self.engine.forward_tokens(x, L.OUT_CLS, torch.float32)
+        hid = ops.linear(cls.to(torch.bfloat16), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
+        logits = ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.num_classes].float()
+        return logits, cls

@@ -1,0 +1,83 @@
+"""Single-operator entry points of libvdr.so (vdr_op_*), used by the per-kernel parity tests and
+the kernel benchmark.  Every tensor must already live on the HIP device; nothing falls back."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _s(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype=torch.bfloat16):
+    lib = L.load()
+    assert x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    L.check(lib.vdr_op_layernorm(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, y.data_ptr(),
+                                 1 if out_dtype == torch.bfloat16 else 0, gamma.data_ptr(), beta.data_ptr(), rows, D,
+                                 float(eps), _s(x)))
+    return y
+
+
+def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None):
+    """x [M,K] bf16, W [N,K] bf16 (for EPI_SWIGLU W/bias must already be gate-pair packed: see pack_w12)."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_contiguous() and W.is_contiguous()
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N // 2 if epilogue == L.EPI_SWIGLU else N), dtype=torch.bfloat16, device=x.device)
+    L.check(lib.vdr_op_linear(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K,
+                              epilogue, variant, _s(x)))
+    return out
+
+
+def pack_w12(w12: torch.Tensor, b12: torch.Tensor):
+    """Interleave SwiGLU x1/x2 rows in blocks of 32 (the layout vdr_set_weight builds for mlp.w12)."""
+    F2 = w12.shape[0]
+    F = F2 // 2
+    assert F % 32 == 0
+    idx = torch.arange(F2)
+    blk, t = idx // 64, idx % 64
+    src = torch.where(t < 32, blk * 32 + t, F + blk * 32 + (t - 32))
+    return w12[src].contiguous(), b12[src].contiguous()
+
+
+def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, variant=0):
+    lib = L.load()
+    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+    assert qkv.shape == (batch * seq, 3 * heads * 64)
+    out = torch.empty((batch * seq, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    L.check(lib.vdr_op_attention(qkv.data_ptr(), out.data_ptr(), batch, seq, heads, variant, _s(qkv)))
+    return out
+
+
+def patch_embed(images, weight, bias, p, pos=None, row_stride=None, row_offset=0, out=None):
+    """images [B,C,H,H] fp32/bf16; weight [D,C,p,p] (any float dtype); returns bf16 [B*row_stride, D]."""
+    lib = L.load()
+    B, Cc, H, _ = images.shape
+    D = weight.shape[0]
+    g = H // p
+    n = g * g
+    K = Cc * p * p
+    Kp = (K + 63) // 64 * 64
+    Wp = torch.zeros((D, Kp), dtype=torch.bfloat16, device=images.device)
+    Wp[:, :K] = weight.reshape(D, K).to(torch.bfloat16)
+    col = torch.empty((B * n * Kp + 4096,), dtype=torch.bfloat16, device=images.device)
+    row_stride = n if row_stride is None else row_stride
+    if out is None:
+        out = torch.zeros((B * row_stride, D), dtype=torch.bfloat16, device=images.device)
+    images = images.contiguous()
+    L.check(lib.vdr_op_patch_embed(images.data_ptr(), 1 if images.dtype == torch.bfloat16 else 0, Wp.data_ptr(),
+                                   _p(bias), _p(pos), col.data_ptr(), out.data_ptr(), B, Cc, H, p, D, row_stride,
+                                   row_offset, _s(images)))
+    return out
