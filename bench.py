@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--model", type=str, default="vit_base16_224")
     ap.add_argument("--micro-batch", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
@@ -93,7 +94,7 @@ def main():
     from oracle import vit_oracle as vo  # weights/images generators + cpu_baseline only
 
     ocfg = vo.CONFIGS[a.model]
-    model = vdr.load_model(a.model, weights=vo.make_weights(ocfg, seed=1), device=dev, micro_batch=a.micro_batch)
+    model = vdr.load_model(a.model, weights=vo.make_weights(ocfg, seed=1), device=dev, micro_batch=a.micro_batch, streams=a.streams)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
@@ -167,7 +168,7 @@ def main():
                "config": {"workload": f"{a.model} {ocfg.img}^2 bf16, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32"
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
-                          "weights": "random-init (seed 1)", "micro_batch": a.micro_batch},
+                          "weights": "random-init (seed 1)", "micro_batch": a.micro_batch, "streams": a.streams},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
                "roofline": roof, "kernels": kern}

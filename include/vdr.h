@@ -88,7 +88,10 @@ typedef struct {
   float ln_eps;       /* 1e-6 timm/DINOv2/SAM, 1e-5 torch default (models_archs.py:136)       */
   int32_t micro_batch;/* images per internal pass (0 = library default sized to the 256 MiB   */
                       /* Infinity Cache); results do not depend on it                         */
-  int32_t reserved[4];
+  int32_t streams;    /* internal HIP streams the micro-batches are spread over (0/1 = the caller's   */
+                      /* stream only); >1 lets kernels of independent micro-batches overlap, e.g. one */
+                      /* GEMM's store-bound epilogue under another's MFMA main loop                   */
+  int32_t reserved[3];
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

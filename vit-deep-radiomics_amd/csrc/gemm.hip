@@ -33,13 +33,13 @@ struct GemmK {
   int off;
   int tiles_n;
   int nwg;
+  int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
 };
 
+// Epilogue math for 4 consecutive output columns n..n+3 of output row m (v2 = SwiGLU gate partner).
 template <int EPI>
-VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc2, int64_t m, int n_base,
-                            int h) {
-  // acc: 32 (n) x 32 (m) tile, this lane owns row m, columns n_base + 8g + 4h + e.
-  if (m >= p.M) return;
+VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, int n) {
+  if (m >= p.M || n >= p.N) return;
   int64_t orow = m;
   int prow = 0;
   if (EPI == EPI_PATCH) {
@@ -48,69 +48,208 @@ VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc
     orow = g * p.gstride + p.off + i;
     prow = p.off + i;
   }
+  if (p.bias) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += b[e];
+  }
+  if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+  }
+  if (EPI == EPI_SWIGLU) {
+    // u is the gate partner (x2); its bias sits 32 packed rows further
+    if (p.bias) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] += b2[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu(v[e]) * u[e];
+  }
+  if (EPI == EPI_BIAS_RESID) {
+    if (p.gamma) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= gm[e];
+    }
+    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + orow * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+  }
+  if (EPI == EPI_PATCH) {
+    if (p.pos) {
+      const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += ps[e];
+    }
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+  int oc = n;
+  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);  // packed column 64*blk + t (t < 32) -> feature 32*blk + t
+  *reinterpret_cast<bf16x4*>(p.C + orow * p.ldc + oc) = o;
+}
+
+// Same math for 8 consecutive columns n..n+7: residual read and output store are 16 bytes per lane
+// (a store wave-instruction costs ~80-100 cycles of the CU's store path whatever its width, so the
+// epilogue is written with the widest ones).
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+template <int EPI>
+VDR_DEV void epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n) {
+  if (m >= p.M || n >= p.N) return;
+  int64_t orow = m;
+  int prow = 0;
+  if (EPI == EPI_PATCH) {
+    const int64_t g = m / p.rpg;
+    const int i = (int)(m - g * p.rpg);
+    orow = g * p.gstride + p.off + i;
+    prow = p.off + i;
+  }
+  if (p.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] += b0[e];
+      v[4 + e] += b1[e];
+    }
+  }
+  if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+  }
+  if (EPI == EPI_SWIGLU) {
+    if (p.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 36);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u[e] += b0[e];
+        u[4 + e] += b1[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
+  }
+  if (EPI == EPI_BIAS_RESID) {
+    if (p.gamma) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] *= g0[e];
+        v[4 + e] *= g1[e];
+      }
+    }
+    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.resid + orow * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+  }
+  if (EPI == EPI_PATCH) {
+    if (p.pos) {
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += p0[e];
+        v[4 + e] += p1[e];
+      }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+  int oc = n;
+  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
+  *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
+}
+
+// Direct-from-accumulator epilogue: this lane owns row m and columns n_base + 8g + 4h + e of a
+// 32 (n) x 32 (m) accumulator tile.
+template <int EPI>
+VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc2, int64_t m, int n_base,
+                            int h) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int n = n_base + 8 * g + 4 * h;
-    if (n >= p.N) continue;
-    float v[4];
+    float v[4], u[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
-    if (p.bias) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += b[e];
+    for (int e = 0; e < 4; ++e) {
+      v[e] = acc[4 * g + e];
+      u[e] = acc2[4 * g + e];
     }
-    if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if (EPI == EPI_SWIGLU) {
-      // acc2 is the gate partner tile (x2); bias for it sits 32 packed rows further
-      float u[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = acc2[4 * g + e];
-      if (p.bias) {
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] += b2[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = silu(v[e]) * u[e];
-    }
-    if (EPI == EPI_BIAS_RESID) {
-      if (p.gamma) {
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= gm[e];
-      }
-      const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + orow * p.ldr + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-    }
-    if (EPI == EPI_PATCH) {
-      if (p.pos) {
-        const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += ps[e];
-      }
-    }
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-    int oc = n;
-    if (EPI == EPI_SWIGLU) {
-      // packed column n = 64*blk + t (t < 32)  ->  output feature 32*blk + t
-      oc = (n >> 6) * 32 + (n & 31);
-    }
-    *reinterpret_cast<bf16x4*>(p.C + orow * p.ldc + oc) = o;
+    epi_quad<EPI>(p, v, u, m, n_base + 8 * g + 4 * h);
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, int EPI>
+// LDS-staged epilogue: the accumulators of a 32 (m) x 64 (n) block go through a wave-private fp32
+// staging image (row stride 272 B: conflict-free ds_write_b128 / ds_read_b128) and come back with
+// 16 lanes per output row, so every global access of the epilogue (bias, residual, store) touches
+// whole 128-B lines instead of 32 rows x 16 B per instruction.
+template <int EPI, int TM, int TN>
+VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int64_t m_base, int n_base, int lane) {
+  constexpr int RS = 272;
+  static_assert(TN % 2 == 0, "column tiles are staged in pairs");
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int jp = 0; jp < TN / 2; ++jp) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = acc[2 * jp + jj][i][4 * g + e];
+          *reinterpret_cast<f32x4*>(stg + l31 * RS + (jj * 32 + 8 * g + 4 * h) * 4) = t;
+        }
+      if (EPI != EPI_SWIGLU) {
+        // 8 lanes per row (8 columns each), 8 rows per instruction: whole 128-B lines, 16-B accesses
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = rr * 8 + (lane >> 3), c8 = lane & 7;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32);
+          const f32x4 t1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32 + 16);
+          float v[8], u[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = u[e] = t0[e];
+            v[4 + e] = u[4 + e] = t1[e];
+          }
+          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8);
+        }
+      } else {
+        // gate pairs: columns 0..31 of the block are x1, 32..63 the matching x2 -> 32 outputs per row
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int row = rr * 16 + (lane >> 2), c8 = lane & 3;
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32 + 16);
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(stg + row * RS + 128 + c8 * 32);
+          const f32x4 g1 = *reinterpret_cast<const f32x4*>(stg + row * RS + 128 + c8 * 32 + 16);
+          float v[8], u[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = a0[e];
+            v[4 + e] = a1[e];
+            u[e] = g0[e];
+            u[4 + e] = g1[e];
+          }
+          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8);
+        }
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmK p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;  // one K-tile of A and W in LDS
   constexpr int NA = BM / 8 / NW;  // global_load_lds instructions per wave for the A tile
   constexpr int NB = BN / 8 / NW;
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
@@ -169,34 +308,65 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmK p) {
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
 
   const int nk = p.K >> 6;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto stage = [&](int buf) {
+    char* dA = sA + buf * STAGE_BYTES;
+    char* dB = sB + buf * STAGE_BYTES;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      glds16(a_src[q], sA + (wave * NA + q) * 1024);
+      glds16(a_src[q], dA + (wave * NA + q) * 1024);
       a_src[q] += 64;
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      glds16(b_src[q], sB + (wave * NB + q) * 1024);
+      glds16(b_src[q], dB + (wave * NB + q) * 1024);
       b_src[q] += 64;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  auto compute = [&](int buf) {
+    const char* cA = sA + buf * STAGE_BYTES;
+    const char* cB = sB + buf * STAGE_BYTES;
+    // fragments double-buffered in registers: the ds_reads of k-step ks+1 are in flight under the
+    // MFMAs of k-step ks (the compiler turns the dependency into a counted lgkmcnt)
+    bf16x8 af[2][TM], bf[2][TN];
+    auto load_frags = [&](int ks, int set) {
+      const int ch = ((2 * ks + h) ^ swz) * 16;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const bf16x8*>(cB + b_off[j] + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(cA + a_off[i] + ch);
+    };
+    load_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int ch = ((2 * ks + h) ^ swz) * 16;
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sA + a_off[i] + ch);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sB + b_off[j] + ch);
+      if (ks < 3) load_frags(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this k-step's MFMAs
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks & 1][j], af[ks & 1][i], acc[j][i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+  };
+  if (PIPE == 0) {
+    // single LDS stage, two barriers per K-tile; latency hidden by 3 co-resident workgroups per CU
+    for (int kt = 0; kt < nk; ++kt) {
+      stage(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(0);
+      __syncthreads();
+    }
+  } else {
+    // two LDS stages, ONE barrier per K-tile: the global_load_lds of tile kt+1 is issued right after
+    // the barrier and lands under the MFMAs of tile kt
+    stage(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile kt has landed for every wave; everyone is done reading the other stage
+      if (kt + 1 < nk) stage((kt + 1) & 1);
+      compute(kt & 1);
+    }
   }
 
   // ---- epilogue: lane owns output row m (per i) and 4-column groups (per j, g)
@@ -215,7 +385,326 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmK p) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+
+// -------------------------------------------------------------------------------------------------
+// Ring-pipelined variant.  K is consumed in 32-deep units; each unit (A rows + W rows, 64-B rows,
+// 16-B chunks XOR-swizzled by (row>>2)&3) lives in one of NST LDS slots.  The global_load_lds of
+// unit s+NST-1 is issued right after the barrier of step s and stays in flight ACROSS the next
+// barriers: the only wait is a counted s_waitcnt vmcnt that retires unit s alone, and the barrier
+// is a raw s_barrier (a __syncthreads() would drain the whole ring).  This keeps (NST-1) units per
+// workgroup streaming from L2 at all times, which is what the per-CU L2->LDS path needs to reach its
+// rate (the earlier variants issue a burst, drain it, and sit at ~half of it).
+// -------------------------------------------------------------------------------------------------
+template <int N>
+VDR_DEV void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 2 : 2)) void gemm_ring_kernel(GemmK p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int UNIT = (BM + BN) * 64;  // bytes of one 32-deep unit
+  constexpr int NA = BM / 16 / NW;      // global_load_lds per wave per unit (16 rows x 64 B each)
+  constexpr int NB = BN / 16 / NW;
+  constexpr int G = NA + NB;
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
+  static_assert((NST - 2) * G <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int wg = xcd_remap(blockIdx.x, p.nwg);
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int srow = lane >> 2;  // row within the 16-row piece
+  const int spc = lane & 3;    // physical 16-B chunk within the 64-B row
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int r = (wave * NA + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int64_t gr = m0 + r;
+    gr = gr < p.M ? gr : p.M - 1;
+    a_src[q] = p.A + gr * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int r = (wave * NB + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int gr = n0 + r;
+    gr = gr < p.N ? gr : p.N - 1;
+    b_src[q] = p.W + (int64_t)gr * p.ldw + c * 8;
+  }
+
+  const int swz = (lane >> 2) & 3;  // == (row >> 2) & 3: tile row bases are multiples of 32
+  int a_off[TM], b_off[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = (wm * TM * 32 + i * 32 + l31) * 64;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = BM * 64 + (wn * TN * 32 + j * 32 + l31) * 64;
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+
+  const int nsteps = p.K >> 5;
+  auto stage = [&](int slot) {
+    char* d = smem + slot * UNIT;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      glds16(a_src[q], d + (wave * NA + q) * 1024);
+      a_src[q] += 32;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      glds16(b_src[q], d + BM * 64 + (wave * NB + q) * 1024);
+      b_src[q] += 32;
+    }
+  };
+  auto compute = [&](int slot) {
+    const char* c0 = smem + slot * UNIT;
+    bf16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ((2 * ks + h) ^ swz) * 16;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8*>(c0 + b_off[j] + ch);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(c0 + a_off[i] + ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][j], af[ks][i], acc[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: units 0 .. NST-2 in flight
+#pragma unroll
+  for (int u = 0; u < NST - 1; ++u)
+    if (u < nsteps) stage(u);
+  int slot = 0, stage_slot = NST - 1;
+  for (int s = 0; s < nsteps; ++s) {
+    const int younger = nsteps - 1 - s;  // units issued after unit s (capped by the ring depth)
+    if (younger >= NST - 2) {
+      wait_vmcnt<(NST - 2) * G>();
+    } else if (NST > 3 && younger == 1) {
+      wait_vmcnt<G>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // unit s landed for every wave; slot of unit s-1 is free
+    if (s + NST - 1 < nsteps && !(p.abl & 4)) stage(stage_slot);
+    if (!(p.abl & 2)) compute(slot);
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    stage_slot = stage_slot + 1 == NST ? 0 : stage_slot + 1;
+  }
+
+  if ((p.abl & 1) && acc[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = m0 + wm * TM * 32 + i * 32 + l31;
+    if (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int j = 0; j + 1 < TN; j += 2)
+        epilogue_store<EPI>(p, acc[j][i], acc[j + 1][i], m, n0 + wn * TN * 32 + j * 32, h);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        epilogue_store<EPI>(p, acc[j][i], acc[j][i], m, n0 + wn * TN * 32 + j * 32, h);
+    }
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Ring variant 2: the barrier of a step sits in the MIDDLE of its MFMAs.
+//   top of step s :  X holds the k-step-0 fragments of unit s (read during step s-1)
+//       read Y <- unit s, k-step 1             | 8 MFMAs on X          (LDS reads under MFMAs)
+//       lgkmcnt(0); vmcnt: retire unit s+1; s_barrier               (unit s is now dead)
+//       global_load_lds unit s+NST -> slot of unit s
+//       read X <- unit s+1, k-step 0           | 8 MFMAs on Y
+// so no wave ever waits on an LDS read right after a barrier, and the loader runs NST-1 units ahead.
+// The epilogue goes through LDS (epilogue_lds) so that all its global traffic is whole lines.
+// -------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(GemmK p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int UNIT = (BM + BN) * 64;
+  constexpr int NA = BM / 16 / NW;
+  constexpr int NB = BN / 16 / NW;
+  constexpr int G = NA + NB;
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
+  static_assert((NST - 1) * G <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int h = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int wg = xcd_remap(blockIdx.x, p.nwg);
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int srow = lane >> 2;
+  const int spc = lane & 3;
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int r = (wave * NA + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int64_t gr = m0 + r;
+    gr = gr < p.M ? gr : p.M - 1;
+    a_src[q] = p.A + gr * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int r = (wave * NB + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int gr = n0 + r;
+    gr = gr < p.N ? gr : p.N - 1;
+    b_src[q] = p.W + (int64_t)gr * p.ldw + c * 8;
+  }
+
+  const int swz = (lane >> 2) & 3;
+  int a_off[TM], b_off[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a_off[i] = (wm * TM * 32 + i * 32 + l31) * 64;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = BM * 64 + (wn * TN * 32 + j * 32 + l31) * 64;
+  const int ch0 = ((0 + h) ^ swz) * 16;  // k-step 0: chunks 0,1
+  const int ch1 = ((2 + h) ^ swz) * 16;  // k-step 1: chunks 2,3
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
+
+  const int nsteps = p.K >> 5;
+  const bool do_epi = __builtin_amdgcn_readfirstlane(p.abl & 1) == 0;
+  auto stage = [&](int slot) {
+    char* d = smem + slot * UNIT;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      glds16(a_src[q], d + (wave * NA + q) * 1024);
+      a_src[q] += 32;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      glds16(b_src[q], d + BM * 64 + (wave * NB + q) * 1024);
+      b_src[q] += 32;
+    }
+  };
+  bf16x8 xa[TM], xb[TN], ya[TM], yb[TN];
+  auto read_frags = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN], int slot, int ch) {
+    const char* c0 = smem + slot * UNIT;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(c0 + b_off[j] + ch);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(c0 + a_off[i] + ch);
+  };
+  auto mfmas = [&](bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[j][i], 0, 0, 0);
+  };
+  // retire unit u: every global_load_lds of units <= u issued by this wave has landed
+  auto retire = [&](int u, int issued_upto) {
+    int younger = issued_upto - u;  // units issued after unit u
+    if (younger >= NST - 1) {
+      wait_vmcnt<(NST - 1) * G>();
+    } else if (younger == NST - 2 && NST >= 3) {
+      wait_vmcnt<(NST - 2) * G>();
+    } else if (younger == 2 && NST >= 5) {
+      wait_vmcnt<2 * G>();
+    } else if (younger == 1 && NST >= 4) {
+      wait_vmcnt<G>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  };
+
+  // prologue: fill the ring
+  int issued = -1;
+#pragma unroll
+  for (int u = 0; u < NST; ++u)
+    if (u < nsteps) {
+      stage(u);
+      issued = u;
+    }
+  retire(0, issued);
+  __builtin_amdgcn_s_barrier();
+  read_frags(xa, xb, 0, ch0);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    mfmas(xa, xb);                       // k-step 0 of unit s (fragments read during step s-1)
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(ya, yb, slot, ch1);       // k-step 1 of unit s: lands under the MFMAs just issued
+    const int nslot = slot + 1 == NST ? 0 : slot + 1;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): unit s fully consumed from LDS by this wave
+    if (s + 1 < nsteps) {
+      retire(s + 1, issued);
+      __builtin_amdgcn_s_barrier();
+      if (s + NST < nsteps) {
+        stage(slot);
+        issued = s + NST;
+      }
+      read_frags(xa, xb, nslot, ch0);    // k-step 0 of unit s+1: lands under the next MFMAs
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(ya, yb);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = nslot;
+  }
+
+  if (!do_epi && acc[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
+  __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
+  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+}
+
+int g_gemm_ablation = 0;
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int E>
+static auto launch_pick() -> void (*)(GemmK) {
+  if constexpr (PIPE >= 20)
+    return gemm_ring2_kernel<WAVES_M, WAVES_N, TM, TN, PIPE - 20, E>;
+  else if constexpr (PIPE >= 10)
+    return gemm_ring_kernel<WAVES_M, WAVES_N, TM, TN, PIPE - 10, E>;
+  else
+    return gemm_kernel<WAVES_M, WAVES_N, TM, TN, PIPE, E>;
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE>
 static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   GemmK k;
@@ -241,11 +730,12 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
   k.nwg = (int)nwg;
+  k.abl = g_gemm_ablation;
   const dim3 grid((unsigned)nwg), block(WAVES_M * WAVES_N * 64);
-  const size_t lds = (size_t)(BM + BN) * 128;
+  const size_t lds = PIPE >= 20 ? (size_t)(BM + BN) * 64 * (PIPE - 20) : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
   case E: {                                                                                       \
-    auto fn = gemm_kernel<WAVES_M, WAVES_N, TM, TN, E>;                                           \
+    auto fn = launch_pick<WAVES_M, WAVES_N, TM, TN, PIPE, E>();                                   \
     if (lds > 65536) {                                                                            \
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds);                                               \
@@ -267,19 +757,45 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   return hipGetLastError();
 }
 
-int gemm_num_variants() { return 3; }
+int gemm_num_variants() { return 16; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
+  g_gemm_ablation = variant / 100;
+  variant %= 100;
   switch (variant) {
     case 0:
     case 1:
-      return launch_cfg<2, 2, 2, 2>(a, epilogue, s);  // 128x128, 4 waves
+      return launch_cfg<2, 2, 2, 2, 0>(a, epilogue, s);  // 128x128, 4 waves, single stage
     case 2:
-      return launch_cfg<2, 2, 4, 2>(a, epilogue, s);  // 256x128, 4 waves (wave 128x64)
+      return launch_cfg<2, 2, 4, 2, 0>(a, epilogue, s);  // 256x128, 4 waves (wave 128x64)
     case 3:
-      return launch_cfg<4, 2, 2, 2>(a, epilogue, s);  // 256x128, 8 waves (wave 64x64)
+      return launch_cfg<4, 2, 2, 2, 0>(a, epilogue, s);  // 256x128, 8 waves (wave 64x64)
+    case 4:
+      return launch_cfg<2, 4, 4, 2, 1>(a, epilogue, s);  // 256x256, 8 waves (wave 128x64), 2 stages
+    case 5:
+      return launch_cfg<4, 2, 2, 4, 1>(a, epilogue, s);  // 256x256, 8 waves (wave 64x128), 2 stages
+    case 6:
+      return launch_cfg<2, 4, 2, 2, 1>(a, epilogue, s);  // 128x256, 8 waves (wave 64x64), 2 stages
+    case 7:
+      return launch_cfg<2, 2, 2, 2, 1>(a, epilogue, s);  // 128x128, 4 waves, 2 stages
+    case 8:
+      return launch_cfg<2, 2, 4, 2, 13>(a, epilogue, s);  // ring: 256x128, 4 waves (wave 128x64), 3 x 24 KB, 2 WG/CU
+    case 9:
+      return launch_cfg<4, 2, 2, 4, 14>(a, epilogue, s);  // ring: 256x256, 8 waves (wave 64x128), 4 x 32 KB
+    case 10:
+      return launch_cfg<2, 2, 2, 4, 13>(a, epilogue, s);  // ring: 128x256, 4 waves (wave 64x128), 3 x 24 KB, 2 WG/CU
+    case 11:
+      return launch_cfg<2, 4, 4, 2, 14>(a, epilogue, s);  // ring: 256x256, 8 waves (wave 128x64), 4 x 32 KB
+    case 12:
+      return launch_cfg<4, 2, 2, 4, 24>(a, epilogue, s);  // ring2: 256x256, 8 waves (wave 64x128), 4 x 32 KB
+    case 13:
+      return launch_cfg<2, 4, 4, 2, 24>(a, epilogue, s);  // ring2: 256x256, 8 waves (wave 128x64), 4 x 32 KB
+    case 14:
+      return launch_cfg<2, 2, 4, 2, 23>(a, epilogue, s);  // ring2: 256x128, 4 waves (wave 128x64), 3 x 24 KB, 2 WG/CU
+    case 15:
+      return launch_cfg<2, 2, 2, 4, 23>(a, epilogue, s);  // ring2: 128x256, 4 waves (wave 64x128), 3 x 24 KB, 2 WG/CU
     default:
       return hipErrorInvalidValue;
   }

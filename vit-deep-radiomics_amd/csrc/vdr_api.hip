@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -64,6 +65,10 @@ struct vdr_model {
               *inw = nullptr, *inb = nullptr;
   bool resolved = false;
   std::string err;
+  // internal streams (cfg.streams > 1)
+  std::vector<hipStream_t> streams;
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_join;
   // profiler
   bool prof = false;
   std::vector<ProfEvent> ev_used, ev_free;
@@ -215,9 +220,42 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
   return w;
 }
 
+int num_streams(const vdr_model* m) { return m->cfg.streams > 1 ? (m->cfg.streams > 8 ? 8 : m->cfg.streams) : 1; }
+
 int default_micro_batch(const vdr_model* m, int batch) {
   if (m->cfg.micro_batch > 0) return m->cfg.micro_batch < batch ? m->cfg.micro_batch : batch;
-  return batch;
+  const int ns = num_streams(m);
+  return (batch + ns - 1) / ns;
+}
+
+// fork: the internal streams wait for everything already enqueued on the caller's stream
+int fork_streams(vdr_model* m, hipStream_t caller) {
+  const int ns = num_streams(m);
+  if (ns == 1) return VDR_OK;
+  if (m->streams.empty()) {
+    m->streams.resize(ns);
+    m->ev_join.resize(ns);
+    for (int i = 0; i < ns; ++i) {
+      if (hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking) != hipSuccess) return VDR_ERR_HIP;
+      if (hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming) != hipSuccess) return VDR_ERR_HIP;
+    }
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess) return VDR_ERR_HIP;
+  }
+  if (hipEventRecord(m->ev_fork, caller) != hipSuccess) return VDR_ERR_HIP;
+  for (int i = 0; i < ns; ++i)
+    if (hipStreamWaitEvent(m->streams[i], m->ev_fork, 0) != hipSuccess) return VDR_ERR_HIP;
+  return VDR_OK;
+}
+
+// join: the caller's stream waits for every internal stream
+int join_streams(vdr_model* m, hipStream_t caller) {
+  const int ns = num_streams(m);
+  if (ns == 1) return VDR_OK;
+  for (int i = 0; i < ns; ++i) {
+    if (hipEventRecord(m->ev_join[i], m->streams[i]) != hipSuccess) return VDR_ERR_HIP;
+    if (hipStreamWaitEvent(caller, m->ev_join[i], 0) != hipSuccess) return VDR_ERR_HIP;
+  }
+  return VDR_OK;
 }
 
 // ---- profiler -----------------------------------------------------------------------------------
@@ -254,6 +292,19 @@ struct Scope {
     if (_e != hipSuccess) return hip_fail(m, _e, what); \
   } while (0)
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// tile configuration per GEMM class; VDR_GEMM_VARIANT overrides all of them (tuning aid)
+int gemm_variant_for(int cls) {
+  static const int forced = env_int("VDR_GEMM_VARIANT", -1);
+  if (forced >= 0) return forced;
+  (void)cls;
+  return 0;
+}
+
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi) {
   GemmArgs g{};
@@ -273,7 +324,7 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
-  VDR_TRY(launch_gemm(g, epi, 0, s), "gemm");
+  VDR_TRY(launch_gemm(g, epi, gemm_variant_for(cls), s), "gemm");
   return VDR_OK;
 }
 
@@ -437,6 +488,9 @@ void vdr_destroy(vdr_handle h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots)
     if (s.dev) hipFree(s.dev);
+  for (auto st : h->streams) hipStreamDestroy(st);
+  for (auto e : h->ev_join) hipEventDestroy(e);
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& e : h->ev_used) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
@@ -529,7 +583,7 @@ int vdr_workspace_bytes(vdr_handle m, int batch, int seq, size_t* out) {
   const int ntok = m->cfg.patch ? m->n_tokens : seq + (m->cfg.has_cls ? 1 : 0);
   if (ntok <= 0) return fail(m, VDR_ERR_INVALID, "seq must be positive for a token model");
   const int mb = default_micro_batch(m, batch);
-  *out = carve(m, nullptr, mb, ntok).total;
+  *out = carve(m, nullptr, mb, ntok).total * num_streams(m);
   return VDR_OK;
 }
 
@@ -547,15 +601,21 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
   if (!m->resolved && (rc = resolve(m))) return rc;
   const int mb_max = default_micro_batch(m, batch);
   const int ntok = m->n_tokens, n = m->n_patches, D = c.dim;
-  const Carve w = carve(m, (char*)workspace, mb_max, ntok);
-  if (w.total > workspace_bytes)
-    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
-  hipStream_t s = (hipStream_t)stream;
+  const int ns = num_streams(m);
+  const size_t per_ws = carve(m, nullptr, mb_max, ntok).total;
+  if (per_ws * ns > workspace_bytes)
+    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(per_ws * ns) + " bytes");
+  hipStream_t caller = (hipStream_t)stream;
+  if (fork_streams(m, caller)) return fail(m, VDR_ERR_HIP, "internal stream setup failed");
   const size_t img_elems = (size_t)c.in_chans * c.img * c.img;
   const size_t in_es = in_dtype == VDR_BF16 ? 2 : 4;
   const int ncls = c.has_cls ? 1 : 0;
-  for (int b0 = 0; b0 < batch; b0 += mb_max) {
+  int chunk = 0;
+  for (int b0 = 0; b0 < batch; b0 += mb_max, ++chunk) {
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
+    const int si = chunk % ns;
+    hipStream_t s = ns == 1 ? caller : m->streams[si];
+    const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* img = (const char*)images + (size_t)b0 * img_elems * in_es;
     {
       Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)mb * img_elems * in_es + 2.0 * mb * n * m->Kp);
@@ -610,6 +670,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     char* o = (char*)out + (size_t)b0 * rows_per_img * out_row_bytes(m, out_dtype);
     if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;
   }
+  if (join_streams(m, caller)) return fail(m, VDR_ERR_HIP, "internal stream join failed");
   return VDR_OK;
 }
 
@@ -629,13 +690,19 @@ int vdr_forward_tokens(vdr_handle m, const void* tokens, int in_dtype, int batch
   const int ncls = c.has_cls ? 1 : 0;
   const int ntok = seq + ncls, D = c.dim;
   const int mb_max = default_micro_batch(m, batch);
-  const Carve w = carve(m, (char*)workspace, mb_max, ntok);
-  if (w.total > workspace_bytes)
-    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
-  hipStream_t s = (hipStream_t)stream;
+  const int ns = num_streams(m);
+  const size_t per_ws = carve(m, nullptr, mb_max, ntok).total;
+  if (per_ws * ns > workspace_bytes)
+    return fail(m, VDR_ERR_WORKSPACE, "workspace too small: need " + std::to_string(per_ws * ns) + " bytes");
+  hipStream_t caller = (hipStream_t)stream;
+  if (fork_streams(m, caller)) return fail(m, VDR_ERR_HIP, "internal stream setup failed");
   const size_t in_es = in_dtype == VDR_BF16 ? 2 : 4;
-  for (int b0 = 0; b0 < batch; b0 += mb_max) {
+  int chunk = 0;
+  for (int b0 = 0; b0 < batch; b0 += mb_max, ++chunk) {
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
+    const int si = chunk % ns;
+    hipStream_t s = ns == 1 ? caller : m->streams[si];
+    const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* tok = (const char*)tokens + (size_t)b0 * seq * D * in_es;
     const int64_t M = (int64_t)mb * ntok;
     if (c.input_ln) {
@@ -653,6 +720,7 @@ int vdr_forward_tokens(vdr_handle m, const void* tokens, int in_dtype, int batch
     char* o = (char*)out + (size_t)b0 * rows_per * out_row_bytes(m, out_dtype);
     if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;
   }
+  if (join_streams(m, caller)) return fail(m, VDR_ERR_HIP, "internal stream join failed");
   return VDR_OK;
 }
 

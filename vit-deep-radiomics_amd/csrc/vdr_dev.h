@@ -32,17 +32,19 @@ VDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // exact-erf GELU, 0.5 x (1 + erf(x / sqrt 2)) (activation="gelu", models_archs.py:133).
 // erfc(|z|) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), used on the complement side for
 // negative x so the tail keeps its relative accuracy.
+// Written branch-free as  gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)  (identical for both
+// signs), which needs no compare/select and keeps the VALU count of the GEMM epilogue low.
 VDR_DEV float gelu_erf(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
+  const float ax = fabsf(x);
+  const float z = ax * 0.70710678118654752f;
   const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = poly * fast_exp2(-z * z * 1.44269504088896341f);  // erfc(|z|)
-  const float half_e = 0.5f * e;
-  return x * (x >= 0.0f ? 1.0f - half_e : half_e);
+  const float e = fast_exp2(z * z * -1.44269504088896341f);
+  const float w = (poly * t) * (e * (0.5f * ax));  // 0.5 |x| erfc(|z|)
+  return fmaxf(x, 0.0f) - w;
 }
 
 VDR_DEV float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-x * 1.44269504088896341f)); }

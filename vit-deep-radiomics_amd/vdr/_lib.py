@@ -26,7 +26,7 @@ class vdr_config(C.Structure):
                 ("heads", C.c_int32), ("layers", C.c_int32), ("mlp_hidden", C.c_int32), ("act", C.c_int32),
                 ("pre_ln", C.c_int32), ("layerscale", C.c_int32), ("has_cls", C.c_int32), ("has_pos", C.c_int32),
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("streams", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)

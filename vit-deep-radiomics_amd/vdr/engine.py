@@ -29,6 +29,7 @@ class VdrConfig:
     input_ln: bool = False
     ln_eps: float = 1e-6
     micro_batch: int = 0
+    streams: int = 0
 
     @property
     def n_patches(self):
@@ -45,6 +46,7 @@ class VdrConfig:
         c.act = L.ACT_SWIGLU if self.act == "swiglu" else L.ACT_GELU
         c.pre_ln, c.layerscale, c.has_cls, c.has_pos = int(self.pre_ln), int(self.layerscale), int(self.has_cls), int(self.has_pos)
         c.input_ln, c.ln_eps, c.micro_batch = int(self.input_ln), float(self.ln_eps), int(self.micro_batch)
+        c.streams = int(self.streams)
         return c
 
 
