@@ -12,6 +12,8 @@
 // bank-conflict free.  The MFMA is issued transposed (W fragment as the A operand, activation
 // fragment as the B operand) so that a lane owns one output ROW and 4 consecutive output columns
 // per register group: the epilogue then reads bias/residual and writes bf16 8 bytes at a time.
+#include <cstdlib>
+
 #include "vdr_dev.h"
 #include "vdr_kernels.h"
 
@@ -33,6 +35,7 @@ struct GemmK {
   int off;
   int tiles_n;
   int nwg;
+  int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
   int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
 };
 
@@ -609,6 +612,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
 
   const int nsteps = p.K >> 5;
+  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    // de-phase the second resident workgroup of every CU by about half a tile: its store-bound
+    // epilogue then runs under its neighbour's MFMA main loop instead of next to its epilogue
+    const long long t0 = clock64();
+    while (clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(64);
+  }
   const bool do_epi = __builtin_amdgcn_readfirstlane(p.abl & 1) == 0;
   auto stage = [&](int slot) {
     char* d = smem + slot * UNIT;
@@ -693,6 +702,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
 }
 
 int g_gemm_ablation = 0;
+int g_gemm_stagger_per_step = -1;
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int E>
 static auto launch_pick() -> void (*)(GemmK) {
@@ -731,6 +741,11 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
   k.nwg = (int)nwg;
   k.abl = g_gemm_ablation;
+  if (g_gemm_stagger_per_step < 0) {
+    const char* e = getenv("VDR_GEMM_STAGGER");
+    g_gemm_stagger_per_step = e && *e ? atoi(e) : 0;
+  }
+  k.stagger = (WAVES_M * WAVES_N == 4) ? g_gemm_stagger_per_step * (a.K >> 5) : 0;
   const dim3 grid((unsigned)nwg), block(WAVES_M * WAVES_N * 64);
   const size_t lds = PIPE >= 20 ? (size_t)(BM + BN) * 64 * (PIPE - 20) : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
@@ -757,7 +772,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   return hipGetLastError();
 }
 
-int gemm_num_variants() { return 16; }
+int gemm_num_variants() { return 18; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
@@ -796,6 +811,10 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
       return launch_cfg<2, 2, 4, 2, 23>(a, epilogue, s);  // ring2: 256x128, 4 waves (wave 128x64), 3 x 24 KB, 2 WG/CU
     case 15:
       return launch_cfg<2, 2, 2, 4, 23>(a, epilogue, s);  // ring2: 128x256, 4 waves (wave 64x128), 3 x 24 KB, 2 WG/CU
+    case 16:
+      return launch_cfg<2, 2, 2, 2, 23>(a, epilogue, s);  // ring2: 128x128, 4 waves (wave 64x64), 3 x 16 KB, 3 WG/CU
+    case 17:
+      return launch_cfg<2, 2, 2, 2, 24>(a, epilogue, s);  // ring2: 128x128, 4 waves (wave 64x64), 4 x 16 KB, 2 WG/CU
     default:
       return hipErrorInvalidValue;
   }

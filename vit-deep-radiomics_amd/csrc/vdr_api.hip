@@ -302,7 +302,7 @@ int gemm_variant_for(int cls) {
   static const int forced = env_int("VDR_GEMM_VARIANT", -1);
   if (forced >= 0) return forced;
   (void)cls;
-  return 0;
+  return 15;  // ring2, 128x256 tile, 4 waves, 3 x 24 KB LDS ring, 2 workgroups per CU (GEMM table)
 }
 
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
@@ -647,7 +647,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       }
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
-      VDR_TRY(launch_gemm(g, EPI_PATCH, 0, s), "patch gemm");
+      VDR_TRY(launch_gemm(g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH), s), "patch gemm");
     }
     if (pe_only) {
       if (out_dtype != VDR_BF16) {
