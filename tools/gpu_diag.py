@@ -75,7 +75,7 @@ def t_gemm():
 
 
 def t_attn():
-    for (B, N, H, v) in [(2, 197, 3, 0), (1, 64, 1, 0), (2, 33, 2, 0), (1, 257, 2, 0), (1, 577, 2, 0), (1, 197, 2, 1), (1, 400, 1, 1)]:
+    for (B, N, H, v) in [(2, 197, 3, 3), (2, 197, 3, 2), (64, 197, 12, 0), (300, 150, 2, 2), (5, 100, 3, 2), (1, 64, 1, 0), (2, 33, 2, 0), (1, 257, 2, 0), (1, 577, 2, 0), (1, 197, 2, 1), (1, 400, 1, 1)]:
         qkv = torch.randn(B * N, 3 * H * 64).bfloat16()
         q, k, vv = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
         ref = torch.nn.functional.scaled_dot_product_attention(q, k, vv).transpose(1, 2).reshape(B * N, H * 64)

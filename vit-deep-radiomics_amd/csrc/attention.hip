@@ -28,6 +28,7 @@ struct AttnK {
   int64_t ld_qkv, ld_out;
   int qt_per_block;  // query tiles handled by one workgroup
   int n_chunks;      // key chunks of NT*32 keys
+  int abl;           // diagnostic: 1 = no compute, 2 = no staging after the first item
 };
 
 template <int NT>
@@ -88,25 +89,36 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
       key = key < p.seq ? key : p.seq - 1;
       glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
     }
-    // V^T: item = (key pair, 8-wide d chunk); pack the pair into one dword per d
-    for (int it = tid; it < NT * 128; it += 256) {
+    // V^T: item = (key pair, 8-wide d chunk); all row loads of a thread are issued before its first
+    // LDS write, then each key pair is packed into one dword per d
+    constexpr int NIT = (NT * 128 + 255) / 256;
+    bf16x8 v0[NIT], v1[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
       const int dc = (it >> 3) & 7;
       const int kp = (it & 7) | ((it >> 6) << 3);
       const int key0 = kc0 + 2 * kp;
-      bf16x8 v0, v1;
+      const int k0 = key0 < p.seq ? key0 : p.seq - 1;
+      const int k1 = key0 + 1 < p.seq ? key0 + 1 : p.seq - 1;
+      v0[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k0 * p.ld_qkv + dc * 8);
+      v1[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k1 * p.ld_qkv + dc * 8);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v0[e] = (bf16_t)0.0f;
-        v1[e] = (bf16_t)0.0f;
-      }
-      if (key0 < p.seq) v0 = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key0 * p.ld_qkv + dc * 8);
-      if (key0 + 1 < p.seq) v1 = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(key0 + 1) * p.ld_qkv + dc * 8);
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
+      if (it < NT * 128) {
+        const int dc = (it >> 3) & 7;
+        const int kp = (it & 7) | ((it >> 6) << 3);
+        const int key0 = kc0 + 2 * kp;
+        const bool ok0 = key0 < p.seq, ok1 = key0 + 1 < p.seq;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        bf16x2 pr;
-        pr[0] = v0[e];
-        pr[1] = v1[e];
-        *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
+        for (int e = 0; e < 8; ++e) {
+          bf16x2 pr;
+          pr[0] = ok0 ? v0[i][e] : (bf16_t)0.0f;
+          pr[1] = ok1 ? v1[i][e] : (bf16_t)0.0f;
+          *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -225,6 +237,259 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Persistent variant for single-chunk sequences (seq <= NT*32, at most 7 query tiles):
+//   one 448-thread workgroup per CU walks the (image, head) items; wave w owns query tile w of the
+//   CURRENT item (7 tiles at seq 197: one per wave, no tail).  K / V^T live in two LDS buffers: at the
+//   top of an item every wave issues its share of the NEXT item's staging loads (K by
+//   global_load_lds straight into the other buffer, V rows into registers), computes its tile while
+//   they are in flight, then packs and writes its V^T share.  One s_barrier per item; the staging
+//   latency that the one-shot kernel exposes at the head of every workgroup (52 % of its wave-cycles
+//   were waits) sits under the MFMAs.
+// -------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_items) {
+  constexpr int KEYS = NT * 32;
+  constexpr int VT_STRIDE = NT * 64 + 8;
+  constexpr int BUF = KEYS * 128 + 64 * VT_STRIDE;
+  constexpr int NCW = 7;                              // waves == query tiles served per item
+  constexpr int KPW = (NT * 4 + NCW - 1) / NCW;       // K pieces (8 rows) per wave
+  constexpr int VPW = (NT * 128 + NCW * 64 - 1) / (NCW * 64);  // V items per lane
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5;
+  const int l31 = lane & 31;
+  const int swz = (lane >> 1) & 7;
+  const int HD = p.heads * 64;
+  const int nqt = (p.seq + 31) >> 5;
+  const float sc = 0.125f * 1.44269504088896341f;
+
+  // ---- staging of one item, split in an issue half and a write half -------------------------------
+  bf16x8 sv0[VPW], sv1[VPW];
+  auto stage_issue = [&](int item, char* buf) {
+    const int b = item / p.heads;
+    const int hd = item - b * p.heads;
+    const bf16_t* kb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64 + HD;
+    const bf16_t* vb = kb + HD;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      const int piece = wave + i * NCW;
+      if (piece < NT * 4) {
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int key = r < p.seq ? r : p.seq - 1;
+        glds16(kb + (int64_t)key * p.ld_qkv + c * 8, buf + piece * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+      int it = tid + i * (NCW * 64);
+      it = it < NT * 128 ? it : NT * 128 - 1;
+      const int dc = (it >> 3) & 7;
+      const int kp = (it & 7) | ((it >> 6) << 3);
+      const int key0 = 2 * kp;
+      const int k0 = key0 < p.seq ? key0 : p.seq - 1;
+      const int k1 = key0 + 1 < p.seq ? key0 + 1 : p.seq - 1;
+      sv0[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k0 * p.ld_qkv + dc * 8);
+      sv1[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k1 * p.ld_qkv + dc * 8);
+    }
+  };
+  auto stage_write = [&](char* buf) {
+    char* sVt = buf + KEYS * 128;
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+      const int it = tid + i * (NCW * 64);
+      if (it < NT * 128) {
+        const int dc = (it >> 3) & 7;
+        const int kp = (it & 7) | ((it >> 6) << 3);
+        const int key0 = 2 * kp;
+        const bool ok0 = key0 < p.seq, ok1 = key0 + 1 < p.seq;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16x2 pr;
+          pr[0] = ok0 ? sv0[i][e] : (bf16_t)0.0f;
+          pr[1] = ok1 ? sv1[i][e] : (bf16_t)0.0f;
+          *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // K pieces landed, V^T written
+  };
+
+  // Q fragments of this wave's query tile (B operand of S^T = K.Q^T): 4 x 16 B straight from global
+  auto load_q = [&](int item, int qt, bf16x8 (&q)[4]) {
+    const int b = item / p.heads;
+    const int hd = item - b * p.heads;
+    int qr = qt * 32 + l31;
+    qr = qr < p.seq ? qr : p.seq - 1;
+    const bf16_t* src = p.qkv + ((int64_t)b * p.seq + qr) * p.ld_qkv + hd * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
+  };
+
+  // compute: one 32-query tile of an item against the staged K / V^T.  Fragment reads run one step
+  // ahead of the MFMAs that consume them, and the exp/convert work of key slice i+1 is issued right
+  // after the MFMAs of slice i so the VALU and the matrix pipe overlap.
+  auto compute_tile = [&](int item, int next_item, int qt, const char* buf, bf16x8 (&qf)[4]) {
+    const int b = item / p.heads;
+    const int hd = item - b * p.heads;
+    bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
+    const char* sK = buf + l31 * 128;
+    const char* sVt = buf + KEYS * 128 + l31 * VT_STRIDE + hh * 8;
+    int kch[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kch[ks] = ((2 * ks + hh) ^ swz) * 16;
+
+    f32x16 s[NT];
+    bf16x8 kf[2];  // K fragments, read one MFMA ahead
+    kf[0] = *reinterpret_cast<const bf16x8*>(sK + kch[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int i = t * 4 + ks;
+        if (i + 1 < NT * 4)
+          kf[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(sK + ((i + 1) >> 2) * 32 * 128 + kch[(i + 1) & 3]);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // qf is dead from here: fetch the next item's Q into it; the loads land under the softmax / P.V
+    if (next_item >= 0) load_q(next_item, qt, qf);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t * 32 + 32 > p.seq) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.seq) s[t][e] = -INFINITY;
+        }
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mb = mx * sc;
+    float lsum = 0.0f;
+    f32x16 o[2];
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
+
+    constexpr int NI = NT * 2;  // 16-key slices
+    bf16x4 vlo[2], vhi[2];      // V^T fragments of the slice in flight (both d halves)
+    bf16x8 pf[2];
+    auto read_v = [&](int it) {
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd) {
+        const char* vrow = sVt + nd * 32 * VT_STRIDE + it * 32;
+        vlo[nd] = *reinterpret_cast<const bf16x4*>(vrow);
+        vhi[nd] = *reinterpret_cast<const bf16x4*>(vrow + 16);
+      }
+    };
+    auto make_p = [&](int it, int set) {
+      const int t = it >> 1, s2 = it & 1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
+        lsum += pv;
+        pf[set][j] = (bf16_t)pv;
+      }
+    };
+    read_v(0);
+    make_p(0, 0);
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      const int cur = it & 1;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd) {
+        bf16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = vlo[nd][j];
+          vf[4 + j] = vhi[nd][j];
+        }
+        o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[cur], o[nd], 0, 0, 0);
+      }
+      if (it + 1 < NI) {
+        read_v(it + 1);            // LDS latency hides under the exp/convert block below
+        make_p(it + 1, cur ^ 1);   // VALU work of the next slice runs while the two MFMAs execute
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = qt * 32 + l31;
+    if (q < p.seq) {
+      bf16_t* dst = ob + (int64_t)q * p.ld_out;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
+        }
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  const bool computes = wave < nqt;  // nqt <= NCW (checked by the launcher)
+  bf16x8 qf[4];
+  stage_issue(item, smem);
+  if (computes) load_q(item, wave, qf);
+  stage_write(smem);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));  // retired by the vmcnt(0) just above
+  int cur = 0;
+  for (; item < n_items; item += gridDim.x) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // buffer `cur` holds this item; the other buffer is free
+    asm volatile("" ::: "memory");
+    const int next = item + gridDim.x;
+    const bool more = next < n_items && !(p.abl & 2);
+    if (more) stage_issue(next, smem + (cur ^ 1) * BUF);
+    if (computes && !(p.abl & 1)) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
+    if (more) stage_write(smem + (cur ^ 1) * BUF);
+    // The next item's Q fragments were fetched by ordinary loads during compute_tile.  Retire them
+    // HERE (they have long landed): otherwise hipcc, which cannot count past the LDS-DMA issued at the
+    // top of the next item, would wait vmcnt(0) at their first use and expose the whole staging latency.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+    cur ^= 1;
+  }
+}
+
+template <int NT>
+static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
+  constexpr size_t lds = 2 * ((size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8));
+  auto fn = attn_persist_kernel<NT>;
+  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int n_items = batch * k.heads;
+  const int grid = n_items < n_cu ? n_items : n_cu;
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(448), lds, s, k, n_items);
+  return hipGetLastError();
+}
+
 template <int NT>
 static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = (size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8);
@@ -243,6 +508,8 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
                             hipStream_t s) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return hipErrorInvalidValue;
   AttnK k;
+  k.abl = variant / 10;
+  variant %= 10;
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
   k.seq = seq;
@@ -258,6 +525,14 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   }
   k.qt_per_block = nqt;
   k.n_chunks = 1;
+  if (variant == 2 || variant == 0) {
+    // persistent warp-specialised kernel (needs a few items per workgroup to pay off)
+    if (seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7>(k, batch, s);  // nqt <= 7 compute waves
+    if (variant == 2) {
+      if (seq <= 128) return launch_persist<4>(k, batch, s);
+      if (seq <= 224) return launch_persist<7>(k, batch, s);
+    }
+  }
   if (seq <= 64) return launch_nt<2>(k, batch, s);
   if (seq <= 128) return launch_nt<4>(k, batch, s);
   if (seq <= 224) return launch_nt<7>(k, batch, s);
