@@ -215,6 +215,9 @@ typedef enum {
  * per class, the summed milliseconds, the launch count and the algorithmic
  * FLOPs and bytes of those launches since the last read / reset. */
 int vdr_profile_enable(vdr_handle h, int on);
+/* Restrict the event bracketing to the kernel classes whose bit (1 << class) is set (default: all).
+ * Timing one class keeps the profiler's cost out of a throughput measurement. */
+int vdr_profile_mask(vdr_handle h, uint32_t class_mask);
 int vdr_profile_read(vdr_handle h, double* ms, int64_t* launches, double* flops, double* bytes,
                      int n /* = VDR_K_COUNT */);
 const char* vdr_kernel_class_name(int k);

@@ -130,6 +130,52 @@ def test_vit_base16_224_headline_config():
     _gate(got, ref["cls"], emu["cls"], gate_l2(12), gate_l2(12), "vit_base cls")
 
 
+def test_vit_large14_336_geometry_dense_tokens():
+    """BASELINE config 4 geometry (ViT-L/14 336^2: 577 tokens -> online-softmax attention, D=1024,
+    H=16, F=4096), depth cut to 2 blocks so the CPU oracle stays in seconds; dense per-patch tokens."""
+    import vdr
+    full = vo.CONFIGS["vit_large14_336"]
+    cfg = vo.VitCfg(full.img, full.patch, 3, full.dim, full.heads, 2, full.mlp_hidden)
+    w = vo.make_weights(cfg, seed=4)
+    x = vo.make_images(cfg, 2, seed=5)
+    ref = vo.forward_images(cfg, w, x)
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    dense = e.forward(x.cuda().to(torch.bfloat16), vdr.OUT_DENSE, torch.bfloat16)
+    assert dense.shape == (2, 576, 1024) and dense.dtype == torch.bfloat16
+    _gate(dense, ref["dense"], emu["dense"], gate_l2(2) + 2e-3, gate_l2(2) + 2e-3, "vit_large14 dense (bf16 out)")
+    _gate(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emu["cls"], gate_l2(2), gate_l2(2), "vit_large14 cls")
+
+
+def test_dinov2_giant14_geometry_swiglu_layerscale():
+    """BASELINE config 5 geometry in bf16 (DINOv2 ViT-g/14: D=1536, H=24, SwiGLU hidden 4096, LayerScale,
+    257 tokens -> 9 key tiles), depth cut to 2 blocks."""
+    import vdr
+    full = vo.CONFIGS["dinov2_giant14_224"]
+    cfg = vo.VitCfg(full.img, full.patch, 3, full.dim, full.heads, 2, full.mlp_hidden, act="swiglu", layerscale=True)
+    w = vo.make_weights(cfg, seed=6)
+    x = vo.make_images(cfg, 3, seed=7)
+    ref = vo.forward_images(cfg, w, x)
+    emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    e = _engine(cfg, w)
+    _gate(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emu["cls"], gate_l2(2), gate_l2(2), "dinov2_giant14 cls")
+    _gate(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emu["dense"], gate_l2(2), gate_l2(2), "dinov2_giant14 dense")
+
+
+def test_streams_and_micro_batches_do_not_change_results():
+    import vdr
+    cfg = SMALL["p14_d192"]
+    w = vo.make_weights(cfg, seed=8, scale=0.05)
+    x = vo.make_images(cfg, 9, seed=9).cuda()
+    a = _engine(cfg, w).forward(x, vdr.OUT_DENSE)
+    vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
+                       mlp_hidden=cfg.mlp_hidden, streams=2, micro_batch=2)
+    e2 = vdr.Engine(vc)
+    e2.load_weights(w)
+    for _ in range(3):
+        assert torch.equal(e2.forward(x, vdr.OUT_DENSE), a)
+
+
 @pytest.mark.parametrize("tag", ["tiny", "refconf", "cfg1"])
 def test_golden_reference_class_tokens(golden_dir, tag):
     """models_archs.TransformerNoduleClassifier golden vectors (made by the reference itself)."""

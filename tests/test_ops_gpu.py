@@ -86,6 +86,19 @@ def test_linear_exact_integers_catches_layout_bugs(ops):
     assert torch.equal(y.float().cpu(), _bf(W).float().t())
 
 
+def test_linear_mixed_tile_heights_exact(ops):
+    """Shapes with more than two tiles per CU make the default GEMM finish with a round of half-height
+    tiles (gemm_ring2_kernel); integer data -> bit-exact against the fp32 reference, every row."""
+    from vdr import EPI_BIAS
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K) in [(30000, 768, 128), (50432, 768, 64)]:
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-3, 4, (N,), generator=g).float()
+        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS)
+        assert torch.equal(y.float().cpu(), x @ W.t() + b), (M, N, K)
+
+
 SHAPES = [(197 * 3, 768, 768), (197 * 2 + 5, 2304, 768), (300, 3072, 768), (260, 768, 3072), (197, 192, 192),
           (1000, 576, 192), (64, 1024, 1024), (257 * 2, 1536, 1536)]
 

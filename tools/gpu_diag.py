@@ -62,6 +62,22 @@ def t_gemm_int():
                 print("    first bad:", [(i, y[tuple(i)].item(), ref[tuple(i)].item()) for i in idx])
 
 
+def t_gemm_split():
+    # enough tiles (> 2 per CU) for the mixed-height last round of the default variant
+    for (M, N, K) in [(30000, 768, 128), (50432, 768, 64), (40000, 1024, 64)]:
+        x = torch.randint(-2, 3, (M, K)).float()
+        W = torch.randint(-2, 3, (N, K)).float()
+        b = torch.randint(-3, 4, (N,)).float()
+        ref = x @ W.t() + b
+        y = ops.linear(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), variant=15).float().cpu()
+        nbad = int((y != ref).sum())
+        print(f"  int gemm (split) {M}x{N}x{K}: mismatches {nbad}/{y.numel()}", flush=True)
+        if nbad:
+            FAILED.append("int gemm split")
+            rows = torch.nonzero((y != ref).any(dim=1)).flatten()
+            print("    bad rows:", rows[:5].tolist(), "...", rows[-5:].tolist(), "count", rows.numel())
+
+
 def t_gemm():
     for (M, N, K) in [(591, 768, 768), (399, 2304, 768), (300, 3072, 768), (260, 768, 3072)]:
         x = torch.randn(M, K).bfloat16()
@@ -109,7 +125,7 @@ def t_model():
 if __name__ == "__main__":
     torch.manual_seed(0)
     print(torch.cuda.get_device_name(0), torch.version.hip, flush=True)
-    for f in (t_ln, t_gemm_int, t_gemm, t_attn, t_pe, t_model):
+    for f in (t_ln, t_gemm_int, t_gemm_split, t_gemm, t_attn, t_pe, t_model):
         print(f.__name__, flush=True)
         guard(f)
     torch.cuda.synchronize()

@@ -35,6 +35,8 @@ struct GemmK {
   int off;
   int tiles_n;
   int nwg;
+  int nwg_big;      // ring2: workgroups [0, nwg_big) use the full tile height, the rest half of it
+  int64_t m_split;  // ring2: first row covered by half-height tiles
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
   int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
 };
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 2 
 // The epilogue goes through LDS (epilogue_lds) so that all its global traffic is whole lines.
 // -------------------------------------------------------------------------------------------------
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(GemmK p) {
+VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, char* smem) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -559,7 +561,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
   constexpr int G = NA + NB;
   static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
   static_assert((NST - 1) * G <= 63, "vmcnt range");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -567,11 +568,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int h = lane >> 5;
   const int l31 = lane & 31;
-
-  const int wg = xcd_remap(blockIdx.x, p.nwg);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int n0 = tn * BN;
 
   const int srow = lane >> 2;
   const int spc = lane & 3;
@@ -612,12 +608,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.0f;
 
   const int nsteps = p.K >> 5;
-  if (p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    // de-phase the second resident workgroup of every CU by about half a tile: its store-bound
-    // epilogue then runs under its neighbour's MFMA main loop instead of next to its epilogue
-    const long long t0 = clock64();
-    while (clock64() - t0 < p.stagger) __builtin_amdgcn_s_sleep(64);
-  }
   const bool do_epi = __builtin_amdgcn_readfirstlane(p.abl & 1) == 0;
   auto stage = [&](int slot) {
     char* d = smem + slot * UNIT;
@@ -701,8 +691,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(Ge
   epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
 }
 
+
+// Workgroups [0, p.nwg_big) compute BM x BN tiles of rows [0, p.m_split); the remaining workgroups
+// compute (BM/2) x BN tiles of rows [p.m_split, M).  The hardware dispatches workgroups in index
+// order, so the half-height tiles form the last, partial round: a tile count that leaves the final
+// round x % full costs x/2 % of a round instead of a whole one (ViT-B proj / fc2: 2.31 rounds of
+// 128 x 256 tiles -> 2 rounds + one round of 64 x 256 tiles).
+template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  if ((int)blockIdx.x < p.nwg_big) {
+    const int wg = xcd_remap(blockIdx.x, p.nwg_big);
+    const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+    gemm_ring2_body<WAVES_M, WAVES_N, TM, TN, NST, EPI>(p, (int64_t)tm * BM, tn * BN, smem);
+  } else {
+    if constexpr (WAVES_M == 2 && (TN % 4) == 0) {
+      // same wave count and BN, half the rows: waves laid out 1 x (2*WAVES_N), wave tile (TM*32) x (TN/2*32)
+      const int wg = xcd_remap(blockIdx.x - p.nwg_big, p.nwg - p.nwg_big);
+      const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+      gemm_ring2_body<1, WAVES_N * 2, TM, TN / 2, NST, EPI>(p, p.m_split + (int64_t)tm * (BM / 2), tn * BN, smem);
+    }
+  }
+}
+
 int g_gemm_ablation = 0;
-int g_gemm_stagger_per_step = -1;
+int g_gemm_split = 0;  // VDR_GEMM_SPLIT=1 enables the mixed-height last round (measured: no gain, the
+                       // dispatcher already back-fills CUs as workgroups retire; kept for A/B)
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int E>
 static auto launch_pick() -> void (*)(GemmK) {
@@ -739,14 +755,50 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.tiles_n = (a.N + BN - 1) / BN;
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
-  k.nwg = (int)nwg;
-  k.abl = g_gemm_ablation;
-  if (g_gemm_stagger_per_step < 0) {
-    const char* e = getenv("VDR_GEMM_STAGGER");
-    g_gemm_stagger_per_step = e && *e ? atoi(e) : 0;
+  {
+    static bool once = false;
+    if (!once) {
+      const char* e = getenv("VDR_GEMM_SPLIT");
+      if (e && *e) g_gemm_split = atoi(e);
+      once = true;
+    }
   }
-  k.stagger = (WAVES_M * WAVES_N == 4) ? g_gemm_stagger_per_step * (a.K >> 5) : 0;
-  const dim3 grid((unsigned)nwg), block(WAVES_M * WAVES_N * 64);
+  k.nwg = (int)nwg;
+  k.nwg_big = (int)nwg;
+  k.m_split = a.M;
+  if (PIPE >= 20 && WAVES_M == 2 && (TN % 4) == 0 && g_gemm_split != 0) {
+    // mixed tile heights: finish with one round of half-height tiles when that is shorter than a
+    // partial round of full ones
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const size_t lds_b = (size_t)(BM + BN) * 64 * (PIPE - 20);
+    int per_cu = (int)(160 * 1024 / lds_b);
+    const int by_waves = 8 / (WAVES_M * WAVES_N);  // launch bound: 2 waves per SIMD
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t slots = (int64_t)n_cu * per_cu;
+    const int64_t full = nwg / slots;
+    const int64_t rem = nwg - full * slots;
+    if (full >= 1 && rem > 0) {
+      const int64_t panels_big = full * slots / k.tiles_n;
+      const int64_t m_split = panels_big * BM;
+      const int64_t small_tiles = (a.M - m_split + BM / 2 - 1) / (BM / 2) * k.tiles_n;
+      if (m_split < a.M && small_tiles <= slots) {
+        k.nwg_big = (int)(panels_big * k.tiles_n);
+        k.m_split = m_split;
+        k.nwg = k.nwg_big + (int)small_tiles;
+      }
+    }
+  }
+  k.abl = g_gemm_ablation;
+  k.stagger = 0;
+
+  const dim3 grid((unsigned)k.nwg), block(WAVES_M * WAVES_N * 64);
   const size_t lds = PIPE >= 20 ? (size_t)(BM + BN) * 64 * (PIPE - 20) : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
   case E: {                                                                                       \

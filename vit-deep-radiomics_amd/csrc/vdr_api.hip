@@ -71,6 +71,7 @@ struct vdr_model {
   std::vector<hipEvent_t> ev_join;
   // profiler
   bool prof = false;
+  uint32_t prof_mask = 0xffffffffu;
   std::vector<ProfEvent> ev_used, ev_free;
   double p_flops[VDR_K_COUNT] = {0}, p_bytes[VDR_K_COUNT] = {0};
   int64_t p_launch[VDR_K_COUNT] = {0};
@@ -264,7 +265,8 @@ struct Scope {
   hipStream_t s;
   ProfEvent e;
   bool on;
-  Scope(vdr_model* m_, hipStream_t s_, int cls, double flops, double bytes) : m(m_), s(s_), on(m_->prof) {
+  Scope(vdr_model* m_, hipStream_t s_, int cls, double flops, double bytes)
+      : m(m_), s(s_), on(m_->prof && ((m_->prof_mask >> cls) & 1u)) {
     if (!on) return;
     if (!m->ev_free.empty()) {
       e = m->ev_free.back();
@@ -817,6 +819,12 @@ int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const fl
 int vdr_profile_enable(vdr_handle m, int on) {
   if (!m) return fail(m, VDR_ERR_INVALID, "null handle");
   m->prof = on != 0;
+  return VDR_OK;
+}
+
+int vdr_profile_mask(vdr_handle m, uint32_t class_mask) {
+  if (!m) return fail(m, VDR_ERR_INVALID, "null handle");
+  m->prof_mask = class_mask;
   return VDR_OK;
 }
 

@@ -48,6 +48,7 @@ SYMBOLS = {
     "vdr_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vdr_op_patch_embed": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vdr_profile_enable": (_I, [_P, _I]),
+    "vdr_profile_mask": (_I, [_P, C.c_uint32]),
     "vdr_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
                               C.POINTER(C.c_double), _I]),
     "vdr_kernel_class_name": (C.c_char_p, [_I]),

@@ -154,7 +154,15 @@ class Engine:
         return out
 
     # ---- profiler ---------------------------------------------------------------------------------
-    def profile(self, on: bool):
+    def profile(self, on: bool, classes=None):
+        """Bracket kernel launches with HIP events; classes = iterable of class names to restrict to."""
+        mask = 0xFFFFFFFF
+        if classes is not None:
+            names = [self.lib.vdr_kernel_class_name(k).decode() for k in range(L.K_COUNT)]
+            mask = 0
+            for c in classes:
+                mask |= 1 << names.index(c)
+        L.check(self.lib.vdr_profile_mask(self.h, mask), self.h)
         L.check(self.lib.vdr_profile_enable(self.h, int(on)), self.h)
 
     def profile_read(self):
