@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vit-deep-radiomics_amd"))
+import torch
+import vdr
+from vdr import ops
+torch.manual_seed(0)
+B, N, H = 256, 197, 12
+qkv = torch.randn(B * N, 3 * H * 64, device="cuda").bfloat16()
+for v in (2, 3):
+    a = ops.attention(qkv, B, N, H, variant=v)
+    bad = 0
+    for i in range(5):
+        b = ops.attention(qkv, B, N, H, variant=v)
+        bad += int((a != b).any())
+    print(f"attention variant {v}: nondeterministic runs {bad}/5", flush=True)
+a2 = ops.attention(qkv, B, N, H, variant=2).float(); a3 = ops.attention(qkv, B, N, H, variant=3).float()
+d = (a2 - a3).abs()
+print("persistent vs one-shot: max abs diff", d.max().item(), "n>1e-2:", int((d > 1e-2).sum()), flush=True)
+# permutation equivariance of attention alone
+perm = torch.randperm(B, device="cuda")
+q3 = qkv.view(B, N, -1)
+ap = ops.attention(q3[perm].reshape(B * N, -1).contiguous(), B, N, H, variant=2).view(B, N, -1)
+print("attention perm-equivariant:", bool(torch.equal(ap, ops.attention(qkv, B, N, H, variant=2).view(B, N, -1)[perm])), flush=True)
+M = B * N
+for (Nn, K, epi) in [(2304, 768, vdr.EPI_BIAS), (768, 768, vdr.EPI_BIAS_RESID), (3072, 768, vdr.EPI_BIAS_GELU), (768, 3072, vdr.EPI_BIAS_RESID)]:
+    x = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(Nn, K, device="cuda") * 0.05).bfloat16(); b = torch.randn(Nn, device="cuda")
+    r = torch.randn(M, Nn, device="cuda").bfloat16() if epi == vdr.EPI_BIAS_RESID else None
+    y0 = ops.linear(x, W, b, resid=r, epilogue=epi, variant=15)
+    bad = 0
+    for i in range(5):
+        y = ops.linear(x, W, b, resid=r, epilogue=epi, variant=15)
+        bad += int((y != y0).any())
+    # row-position independence: shift rows by 1000
+    xs = torch.roll(x, 1000, 0); rs = torch.roll(r, 1000, 0) if r is not None else None
+    ys = ops.linear(xs, W, b, resid=rs, epilogue=epi, variant=15)
+    print(f"gemm N{Nn} K{K} epi{epi}: nondeterministic {bad}/5; roll-equivariant {bool(torch.equal(torch.roll(y0, 1000, 0), ys))}", flush=True)
+x = torch.randn(M, 768, device="cuda").bfloat16(); g = torch.ones(768, device="cuda"); bb = torch.zeros(768, device="cuda")
+l0 = ops.layernorm(x, g, bb, 1e-6)
+print("layernorm roll-equivariant:", bool(torch.equal(torch.roll(l0, 1000, 0), ops.layernorm(torch.roll(x, 1000, 0), g, bb, 1e-6))))

@@ -175,9 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
-          const bf16_t pb = (bf16_t)pv;
-          lsum += (float)pb;  // normalise by the sum of what is actually multiplied into O
-          pf[j] = pb;
+          lsum += pv;  // fp32 row sum (same order in the persistent kernel: results are bitwise equal)
+          pf[j] = (bf16_t)pv;
         }
         const int koff = (t * 32 + s2 * 16 + 4 * hh) * 2;
 #pragma unroll

@@ -370,7 +370,8 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
       return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-      VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, 0, s), "attention");
+      static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+      VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
     }
     if (c.pre_ln) {
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
