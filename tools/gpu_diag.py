@@ -51,7 +51,7 @@ def t_gemm_int():
         W = torch.randint(-2, 3, (N, K)).float()
         b = torch.randint(-3, 4, (N,)).float()
         ref = x @ W.t() + b
-        for v in (0, 12, 14, 15, 16, 17):
+        for v in (0, 15, 18, 19, 20, 21):
             y = ops.linear(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), variant=v).float().cpu()
             nbad = int((y != ref).sum())
             print(f"  int gemm {M}x{N}x{K} variant {v}: mismatches {nbad}/{y.numel()}", flush=True)

@@ -697,8 +697,14 @@ VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, cha
 // order, so the half-height tiles form the last, partial round: a tile count that leaves the final
 // round x % full costs x/2 % of a round instead of a whole one (ViT-B proj / fc2: 2.31 rounds of
 // 128 x 256 tiles -> 2 rounds + one round of 64 x 256 tiles).
+// waves per SIMD the register allocator must leave room for: 64-register accumulators (2x2 MFMA tiles
+// per wave) run 4 waves per SIMD (16 per CU) -- the per-CU load rate scales with the number of waves
+// that issue vector-memory instructions (measured: 35 GB/s with 4 waves, 75-79 GB/s with 8)
+template <int TILES>
+constexpr int ring2_min_waves() { return TILES <= 4 ? 4 : 2; }
+
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_ring2_kernel(GemmK p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, ring2_min_waves<TM * TN>()) void gemm_ring2_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -799,7 +805,10 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.stagger = 0;
 
   const dim3 grid((unsigned)k.nwg), block(WAVES_M * WAVES_N * 64);
-  const size_t lds = PIPE >= 20 ? (size_t)(BM + BN) * 64 * (PIPE - 20) : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
+  const size_t lds_ring2 = (size_t)(BM + BN) * 64 * (PIPE - 20) > (size_t)WAVES_M * WAVES_N * 32 * 272
+                               ? (size_t)(BM + BN) * 64 * (PIPE - 20)
+                               : (size_t)WAVES_M * WAVES_N * 32 * 272;
+  const size_t lds = PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
   case E: {                                                                                       \
     auto fn = launch_pick<WAVES_M, WAVES_N, TM, TN, PIPE, E>();                                   \
@@ -824,7 +833,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   return hipGetLastError();
 }
 
-int gemm_num_variants() { return 18; }
+int gemm_num_variants() { return 22; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
@@ -867,6 +876,14 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
       return launch_cfg<2, 2, 2, 2, 23>(a, epilogue, s);  // ring2: 128x128, 4 waves (wave 64x64), 3 x 16 KB, 3 WG/CU
     case 17:
       return launch_cfg<2, 2, 2, 2, 24>(a, epilogue, s);  // ring2: 128x128, 4 waves (wave 64x64), 4 x 16 KB, 2 WG/CU
+    case 18:
+      return launch_cfg<4, 4, 2, 2, 24>(a, epilogue, s);  // ring2: 256x256, 16 waves (wave 64x64), 4 x 32 KB
+    case 19:
+      return launch_cfg<2, 4, 2, 2, 23>(a, epilogue, s);  // ring2: 128x256, 8 waves (wave 64x64), 3 x 24 KB, 2 WG/CU
+    case 20:
+      return launch_cfg<4, 2, 2, 2, 23>(a, epilogue, s);  // ring2: 256x128, 8 waves (wave 64x64), 3 x 24 KB, 2 WG/CU
+    case 21:
+      return launch_cfg<4, 4, 2, 2, 23>(a, epilogue, s);  // ring2: 256x256, 16 waves (wave 64x64), 3 x 32 KB
     default:
       return hipErrorInvalidValue;
   }

@@ -303,8 +303,14 @@ int env_int(const char* name, int dflt) {
 int gemm_variant_for(int cls) {
   static const int forced = env_int("VDR_GEMM_VARIANT", -1);
   if (forced >= 0) return forced;
-  (void)cls;
-  return 15;  // ring2, 128x256 tile, 4 waves, 3 x 24 KB LDS ring, 2 workgroups per CU (GEMM table)
+  // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
+  // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
+  switch (cls) {
+    case VDR_K_GEMM_QKV:
+      return 21;  // ring2 256x256, 16 waves, 3 x 32 KB ring
+    default:
+      return 19;  // ring2 128x256, 8 waves, 3 x 24 KB ring, 2 workgroups per CU
+  }
 }
 
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
