@@ -186,8 +186,19 @@ def main():
             kern[k] = e
         dv = prof_dom[dom]
         ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
+        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r01_pmc_traffic.*): PMC counters cannot be
+        # collected from inside this process, so the number is the profiled one for the same launch shape
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS)", "attention": "attention"}.get(dom)
+            if key in pm and a.model == "vit_base16_224" and B == 256:
+                traffic = round((pm[key]["read_mb_corrected"] + pm[key]["write_mb"]) * 1e6)
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.txt)",
                 "avg_launch_ms": round(dv["ms"] / dv["launches"], 4),
                 "flops_per_launch": dv["flops"] / dv["launches"],
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
