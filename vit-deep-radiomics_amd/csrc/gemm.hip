@@ -37,6 +37,10 @@ struct GemmK {
   int nwg;
   int nwg_big;      // ring2: workgroups [0, nwg_big) use the full tile height, the rest half of it
   int64_t m_split;  // ring2: first row covered by half-height tiles
+  const float* ln_stats;
+  const float* colsum;
+  float* ln_part;
+  int64_t part_stride;
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
   int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
 };
@@ -102,8 +106,10 @@ VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, i
 // epilogue is written with the widest ones).
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 template <int EPI>
-VDR_DEV void epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n) {
-  if (m >= p.M || n >= p.N) return;
+VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2) {
+  sum1 = 0.0f;
+  sum2 = 0.0f;
+  if (m >= p.M || n >= p.N) return -1;
   int64_t orow = m;
   int prow = 0;
   if (EPI == EPI_PATCH) {
@@ -111,6 +117,27 @@ VDR_DEV void epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, in
     const int i = (int)(m - g * p.rpg);
     orow = g * p.gstride + p.off + i;
     prow = p.off + i;
+  }
+  if (p.ln_stats) {
+    // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
+    // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
+    const float mu = p.ln_stats[2 * m], rs = p.ln_stats[2 * m + 1];
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.colsum + n);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = rs * (v[e] - mu * c0[e]);
+      v[4 + e] = rs * (v[4 + e] - mu * c1[e]);
+    }
+    if (EPI == EPI_SWIGLU) {
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.colsum + n + 32);
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 36);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u[e] = rs * (u[e] - mu * d0[e]);
+        u[4 + e] = rs * (u[4 + e] - mu * d1[e]);
+      }
+    }
   }
   if (p.bias) {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -165,10 +192,16 @@ VDR_DEV void epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, in
   }
   bf16x8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+  for (int e = 0; e < 8; ++e) {
+    o[e] = (bf16_t)v[e];
+    const float r = (float)o[e];  // statistics of what the consumer will actually read
+    sum1 += r;
+    sum2 = fmaf(r, r, sum2);
+  }
   int oc = n;
   if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
   *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
+  return orow;
 }
 
 // Direct-from-accumulator epilogue: this lane owns row m and columns n_base + 8g + 4h + e of a
@@ -223,7 +256,23 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
             v[e] = u[e] = t0[e];
             v[4 + e] = u[4 + e] = t1[e];
           }
-          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8);
+          float s1, s2;
+          const int64_t orow = epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2);
+          if (p.ln_part) {
+            // the 8 lanes of a row hold its 64 columns of this block: (sum, sumsq) -> one slot per
+            // (row, 64-column group), written exactly once: no atomics, no zeroing, deterministic
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+              s1 += __shfl_xor(s1, o, 64);
+              s2 += __shfl_xor(s2, o, 64);
+            }
+            const int grp = (n_base + jp * 64) >> 6;
+            if (c8 == 0 && orow >= 0 && n_base + jp * 64 < p.N) {
+              float* dst = p.ln_part + ((int64_t)grp * p.part_stride + orow) * 2;
+              dst[0] = s1;
+              dst[1] = s2;
+            }
+          }
         }
       } else {
         // gate pairs: columns 0..31 of the block are x1, 32..63 the matching x2 -> 32 outputs per row
@@ -242,7 +291,8 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
             u[e] = g0[e];
             u[4 + e] = g1[e];
           }
-          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8);
+          float s1, s2;
+          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2);
         }
       }
     }
@@ -801,6 +851,10 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
       }
     }
   }
+  k.ln_stats = a.ln_stats;
+  k.colsum = a.colsum;
+  k.ln_part = a.ln_part;
+  k.part_stride = a.part_stride;
   k.abl = g_gemm_ablation;
   k.stagger = 0;
 
@@ -840,6 +894,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
   g_gemm_ablation = variant / 100;
   variant %= 100;
+  if ((a.ln_stats || a.ln_part) && variant < 12) return hipErrorInvalidValue;  // needs epilogue_lds (ring2)
+  if (a.ln_part && (a.N & 63)) return hipErrorInvalidValue;
   switch (variant) {
     case 0:
     case 1:

@@ -323,4 +323,69 @@ hipError_t launch_gather_rows(const void* x, void* y, int out_bf16, int64_t rows
   return hipGetLastError();
 }
 
+// (sum, sumsq) partials per 64-column group -> (mean, rstd) per row.  The sums come from the producing
+// GEMM's epilogue; variance = E[x^2] - mean^2 evaluated in double from the fp32 partials.
+__global__ __launch_bounds__(64) void ln_finalize_kernel(const float* __restrict__ part, int groups, int64_t stride,
+                                                          float* __restrict__ stats, int64_t rows, float inv_d, float eps) {
+  const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (r >= rows) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int g0 = 0; g0 < groups; g0 += 8) {
+    float2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // 8 independent loads in flight (coalesced across the wave)
+      const int g = g0 + j < groups ? g0 + j : groups - 1;
+      v[j] = *reinterpret_cast<const float2*>(part + ((int64_t)g * stride + r) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (g0 + j < groups) {
+        s1 += (double)v[j].x;
+        s2 += (double)v[j].y;
+      }
+  }
+  const double mean = s1 * (double)inv_d;
+  double var = s2 * (double)inv_d - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  float2 o;
+  o.x = (float)mean;
+  o.y = (float)(1.0 / sqrt(var + (double)eps));
+  *reinterpret_cast<float2*>(stats + r * 2) = o;
+}
+
+hipError_t launch_ln_finalize(const float* part, int groups, int64_t stride, float* stats, int64_t rows, int D,
+                              float eps, hipStream_t s) {
+  if (rows <= 0 || groups <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, part, groups, stride,
+                     stats, rows, 1.0f / (float)D, eps);
+  return hipGetLastError();
+}
+
+// x[b*row_stride][:] = cls + pos[0], one wave per (image, 64-column group), plus that group's partial sums
+__global__ __launch_bounds__(64) void cls_rows_stats_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                            bf16_t* __restrict__ x, float* __restrict__ part,
+                                                            int64_t part_stride, int groups, int64_t row_stride, int D) {
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int d = g * 64 + threadIdx.x;
+  const int64_t row = (int64_t)b * row_stride;
+  const bf16_t o = (bf16_t)(cls[d] + (pos ? pos[d] : 0.0f));
+  x[row * D + d] = o;
+  const float r = (float)o;
+  const float s1 = wave_sum(r), s2 = wave_sum(r * r);
+  if (threadIdx.x == 0) {
+    float* dst = part + ((int64_t)g * part_stride + row) * 2;
+    dst[0] = s1;
+    dst[1] = s2;
+  }
+}
+
+hipError_t launch_cls_rows_stats(const float* cls, const float* pos, void* x, float* part, int64_t part_stride,
+                                 int batch, int64_t row_stride, int D, hipStream_t s) {
+  if (D & 63) return hipErrorInvalidValue;
+  const int groups = D / 64;
+  hipLaunchKernelGGL(cls_rows_stats_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0, s, cls, pos, (bf16_t*)x, part,
+                     part_stride, groups, row_stride, D);
+  return hipGetLastError();
+}
+
 }  // namespace vdr

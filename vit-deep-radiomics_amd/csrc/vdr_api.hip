@@ -39,11 +39,16 @@ struct WSlot {
   int64_t rows, cols; // logical matrix shape for MAT kinds
   void* dev = nullptr;
   bool set = false;
+  std::vector<float> host;  // fp32 copy kept until resolve() (LayerNorm folding needs it)
 };
 
 struct LayerW {
   const float *n1w, *n1b, *n2w, *n2b, *bqkv, *bproj, *b1, *b2, *ls1, *ls2;
   const void *wqkv, *wproj, *w1, *w2;
+  // LayerNorm folded into the consuming GEMM (pre-LN image models): W' = W.diag(gamma) in bf16,
+  // colsum[n] = sum_k W'[n][k], tbias[n] = sum_k beta[k] W[n][k] + b[n]
+  void *wqkv_f = nullptr, *w1_f = nullptr;
+  float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
 
 struct ProfEvent {
@@ -64,6 +69,7 @@ struct vdr_model {
   const float *b_patch = nullptr, *cls = nullptr, *pos = nullptr, *normw = nullptr, *normb = nullptr,
               *inw = nullptr, *inb = nullptr;
   bool resolved = false;
+  bool ln_fuse = false;
   std::string err;
   // internal streams (cfg.streams > 1)
   std::vector<hipStream_t> streams;
@@ -78,6 +84,14 @@ struct vdr_model {
 };
 
 namespace {
+
+#define VDR_TRY(expr, what)                         \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return hip_fail(m, _e, what); \
+  } while (0)
+
+int hip_fail(vdr_handle h, hipError_t e, const char* what);
 
 int fail(vdr_handle h, int code, const std::string& msg) {
   if (h) h->err = msg;
@@ -148,9 +162,60 @@ const void* dev_of(vdr_model* m, const std::string& name) {
   return it == m->index.end() ? nullptr : m->slots[it->second].dev;
 }
 
+float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+const std::vector<float>* host_of(vdr_model* m, const std::string& name) {
+  auto it = m->index.find(name);
+  return it == m->index.end() ? nullptr : &m->slots[it->second].host;
+}
+
+bool ln_fusion_wanted(const vdr_model* m) {
+  const vdr_config& c = m->cfg;
+  const char* e = getenv("VDR_LN_FUSE");
+  if (e && *e && atoi(e) == 0) return false;
+  return c.patch && c.pre_ln && !c.input_ln && (c.dim % 64) == 0;
+}
+
+// W' = W.diag(gamma) (bf16), colsum, tbias for one linear layer; `perm` (optional) maps packed row -> source row
+int fold_ln(vdr_model* m, const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& gam,
+            const std::vector<float>& bet, int64_t N, int64_t K, const std::vector<int64_t>* perm, void** wf_dev,
+            float** colsum_dev, float** tbias_dev) {
+  std::vector<uint16_t> wf((size_t)N * K);
+  std::vector<float> cs(N), tb(N);
+  for (int64_t pr = 0; pr < N; ++pr) {
+    const int64_t n = perm ? (*perm)[pr] : pr;
+    const float* w = &W[(size_t)n * K];
+    double s = 0.0, t = 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+      const uint16_t h = f32_to_bf16(gam[k] * w[k]);
+      wf[(size_t)pr * K + k] = h;
+      s += (double)bf16_to_f32(h);
+      t += (double)bet[k] * (double)w[k];
+    }
+    cs[pr] = (float)s;
+    tb[pr] = (float)(t + (double)b[n]);
+  }
+  if (!*wf_dev) VDR_TRY(hipMalloc(wf_dev, wf.size() * 2 + 256), "hipMalloc(folded weight)");
+  if (!*colsum_dev) VDR_TRY(hipMalloc((void**)colsum_dev, (size_t)N * 4 + 256), "hipMalloc(colsum)");
+  if (!*tbias_dev) VDR_TRY(hipMalloc((void**)tbias_dev, (size_t)N * 4 + 256), "hipMalloc(tbias)");
+  VDR_TRY(hipMemcpy(*wf_dev, wf.data(), wf.size() * 2, hipMemcpyHostToDevice), "hipMemcpy(folded weight)");
+  VDR_TRY(hipMemcpy(*colsum_dev, cs.data(), (size_t)N * 4, hipMemcpyHostToDevice), "hipMemcpy(colsum)");
+  VDR_TRY(hipMemcpy(*tbias_dev, tb.data(), (size_t)N * 4, hipMemcpyHostToDevice), "hipMemcpy(tbias)");
+  return VDR_OK;
+}
+
 int resolve(vdr_model* m) {
   for (auto& s : m->slots)
     if (!s.set) return fail(m, VDR_ERR_INCOMPLETE, "weight not set: " + s.name);
+  if (ln_fusion_wanted(m))
+    for (auto& s : m->slots)
+      if (s.host.empty())
+        return fail(m, VDR_ERR_INCOMPLETE, "weights changed after the first forward: set every weight again (" + s.name + ")");
   const vdr_config& c = m->cfg;
   m->w_patch = dev_of(m, "patch_embed.proj.weight");
   m->b_patch = (const float*)dev_of(m, "patch_embed.proj.bias");
@@ -186,6 +251,32 @@ int resolve(vdr_model* m) {
       L.b2 = (const float*)dev_of(m, p + "mlp.fc2.bias");
     }
   }
+  m->ln_fuse = ln_fusion_wanted(m);
+  if (m->ln_fuse) {
+    VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+    const int64_t D = c.dim, F = c.mlp_hidden;
+    for (int i = 0; i < c.layers; ++i) {
+      const std::string p = "blocks." + std::to_string(i) + ".";
+      LayerW& L = m->layers[i];
+      int rc = fold_ln(m, *host_of(m, p + "attn.qkv.weight"), *host_of(m, p + "attn.qkv.bias"), *host_of(m, p + "norm1.weight"),
+                       *host_of(m, p + "norm1.bias"), 3 * D, D, nullptr, &L.wqkv_f, &L.sqkv, &L.tqkv);
+      if (rc) return rc;
+      if (c.act == VDR_ACT_SWIGLU) {
+        std::vector<int64_t> perm(2 * F);
+        for (int64_t pr = 0; pr < 2 * F; ++pr) {
+          const int64_t blk = pr / 64, t = pr % 64;
+          perm[pr] = t < 32 ? blk * 32 + t : F + blk * 32 + (t - 32);
+        }
+        rc = fold_ln(m, *host_of(m, p + "mlp.w12.weight"), *host_of(m, p + "mlp.w12.bias"), *host_of(m, p + "norm2.weight"),
+                     *host_of(m, p + "norm2.bias"), 2 * F, D, &perm, &L.w1_f, &L.s1, &L.t1);
+      } else {
+        rc = fold_ln(m, *host_of(m, p + "mlp.fc1.weight"), *host_of(m, p + "mlp.fc1.bias"), *host_of(m, p + "norm2.weight"),
+                     *host_of(m, p + "norm2.bias"), F, D, nullptr, &L.w1_f, &L.s1, &L.t1);
+      }
+      if (rc) return rc;
+    }
+  }
+  for (auto& sl : m->slots) std::vector<float>().swap(sl.host);  // host copies are no longer needed
   m->resolved = true;
   return VDR_OK;
 }
@@ -193,6 +284,8 @@ int resolve(vdr_model* m) {
 // ---- workspace carving ------------------------------------------------------------------------
 struct Carve {
   char *x, *h, *qkv, *o, *u;
+  float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
+  int64_t Mp;
   size_t total;
 };
 
@@ -217,6 +310,9 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
     if (colb > ub) ub = colb;
   }
   w.u = take(ub);
+  w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
+  w.stats = (float*)take(Mp * 8);
+  w.Mp = (int64_t)Mp;
   w.total = off;
   return w;
 }
@@ -288,12 +384,6 @@ struct Scope {
   }
 };
 
-#define VDR_TRY(expr, what)                         \
-  do {                                              \
-    hipError_t _e = (expr);                         \
-    if (_e != hipSuccess) return hip_fail(m, _e, what); \
-  } while (0)
-
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -313,9 +403,20 @@ int gemm_variant_for(int cls) {
   }
 }
 
+struct LnFold {
+  const float* stats = nullptr;   // consumer: (mean, rstd) per row
+  const float* colsum = nullptr;  // consumer: column sums of the folded weight
+  float* part = nullptr;          // producer: partial sums out
+  int64_t part_stride = 0;
+};
+
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
-         const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi) {
+         const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold()) {
   GemmArgs g{};
+  g.ln_stats = ln.stats;
+  g.colsum = ln.colsum;
+  g.ln_part = ln.part;
+  g.part_stride = ln.part_stride;
   g.A = A;
   g.W = W;
   g.bias = bias;
@@ -365,6 +466,42 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
   const int64_t M = (int64_t)mb * ntok;
   const bool sw = c.act == VDR_ACT_SWIGLU;
   int rc;
+  if (c.pre_ln && m->ln_fuse) {
+    // LayerNorm never materialised: producers leave (sum, sumsq) partials, a tiny kernel turns them into
+    // (mean, rstd), the consuming GEMM applies them in its epilogue (weights pre-multiplied by gamma).
+    const int groups = D / 64;
+    LnFold prod;
+    prod.part = w.part;
+    prod.part_stride = w.Mp;
+    for (int i = 0; i < c.layers; ++i) {
+      const LayerW& L = m->layers[i];
+      LnFold cons;
+      cons.stats = w.stats;
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
+        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
+      }
+      cons.colsum = L.sqkv;
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons)))
+        return rc;
+      {
+        Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
+        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
+      }
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
+        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
+      }
+      cons.colsum = L.s1;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
+        return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod))) return rc;
+    }
+    return VDR_OK;
+  }
   for (int i = 0; i < c.layers; ++i) {
     const LayerW& L = m->layers[i];
     const void* attn_in = w.x;
@@ -497,6 +634,14 @@ void vdr_destroy(vdr_handle h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots)
     if (s.dev) hipFree(s.dev);
+  for (auto& L : h->layers) {
+    if (L.wqkv_f) hipFree(L.wqkv_f);
+    if (L.w1_f) hipFree(L.w1_f);
+    if (L.sqkv) hipFree(L.sqkv);
+    if (L.tqkv) hipFree(L.tqkv);
+    if (L.s1) hipFree(L.s1);
+    if (L.t1) hipFree(L.t1);
+  }
   for (auto st : h->streams) hipStreamDestroy(st);
   for (auto e : h->ev_join) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -580,6 +725,7 @@ int vdr_set_weight(vdr_handle m, const char* name, const float* host, const int6
       break;
     }
   }
+  s.host.assign(host, host + numel);
   if (!s.dev) VDR_TRY(hipMalloc(&s.dev, bytes + 256), "hipMalloc(weight)");
   VDR_TRY(hipMemcpy(s.dev, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(weight)");
   s.set = true;
@@ -644,6 +790,10 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       g.ldw = m->Kp;
       g.ldc = D;
       g.ldr = D;
+      if (m->ln_fuse && !pe_only) {
+        g.ln_part = w.part;
+        g.part_stride = w.Mp;
+      }
       if (pe_only && out_dtype == VDR_BF16) {
         g.C = (char*)out + (size_t)b0 * n * D * 2;
         g.omap = RowMap{n, n, 0};
@@ -668,7 +818,10 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     }
     if (c.has_cls) {
       Scope sc(m, s, VDR_K_ASSEMBLE, 0.0, (double)mb * D * 2);
-      VDR_TRY(launch_cls_rows(m->cls, m->pos, w.x, mb, ntok, D, s), "cls rows");
+      if (m->ln_fuse)
+        VDR_TRY(launch_cls_rows_stats(m->cls, m->pos, w.x, w.part, w.Mp, mb, ntok, D, s), "cls rows");
+      else
+        VDR_TRY(launch_cls_rows(m->cls, m->pos, w.x, mb, ntok, D, s), "cls rows");
     }
     if (c.input_ln) {
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.x, 1, m->inw, m->inb, (int64_t)mb * ntok, identity_map())))

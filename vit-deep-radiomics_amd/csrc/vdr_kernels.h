@@ -27,6 +27,13 @@ struct GemmArgs {
   int N, K;
   int64_t lda, ldw, ldc, ldr;
   RowMap omap;        // output row map (EPI_PATCH); identity otherwise
+  // LayerNorm folded into the GEMM (pre-LN models):
+  //   consumer side: y = r_m * (x.W'^T - mu_m * colsum) + bias', with (mu_m, r_m) = ln_stats[m]
+  const float* ln_stats = nullptr;  // [M][2] fp32 (mean, rstd) or null
+  const float* colsum = nullptr;    // [N] fp32: sum_k W'[n][k]
+  //   producer side: per output row and 64-column group, (sum, sum of squares) of the bf16 outputs
+  float* ln_part = nullptr;         // [N/64][part_stride][2] fp32 or null
+  int64_t part_stride = 0;
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
@@ -64,6 +71,15 @@ hipError_t launch_cls_rows(const float* cls, const float* pos, void* x, int batc
 // token assembly for the token model: x[b*(S+1)+1+i] = tok[b*S+i] (+pos), x[b*(S+1)] = cls (+pos[0]); bf16 out
 hipError_t launch_assemble_tokens(const void* tok, int in_bf16, const float* cls, const float* pos,
                                   void* x, int batch, int seq, int D, int has_cls, hipStream_t s);
+
+// LayerNorm statistics kept apart from the normalisation (the normalisation itself is folded into
+// the consuming GEMM): part [groups][stride][2] (sum, sumsq per 64-column group) -> stats [rows][2]
+// (mean, rstd)
+hipError_t launch_ln_finalize(const float* part, int groups, int64_t stride, float* stats, int64_t rows, int D,
+                              float eps, hipStream_t s);
+// x[b*row_stride][:] = cls + pos[0] as launch_cls_rows, plus that row's partial sums
+hipError_t launch_cls_rows_stats(const float* cls, const float* pos, void* x, float* part, int64_t part_stride,
+                                 int batch, int64_t row_stride, int D, hipStream_t s);
 
 // y[r] = x[imap(r)], bf16 -> bf16 / fp32
 hipError_t launch_gather_rows(const void* x, void* y, int out_bf16, int64_t rows, int D, RowMap imap,
