@@ -124,7 +124,9 @@ def main():
     images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g).to(torch.bfloat16).to(dev)  # synthetic [0,1)
     total = B * world
     feats = torch.empty((total, D), dtype=torch.float32, device=dev)  # final row-ordered [N, D] matrix
-    mine = feats[rank * B:(rank + 1) * B]
+    # single GPU: the forward writes the matrix directly; multi GPU: each rank's rows go to a send buffer
+    # and ONE all-gather lays them out in rank (= dataset) order
+    mine = feats if world == 1 else torch.empty((B, D), dtype=torch.float32, device=dev)
 
     def step():
         eng.forward_into(images, mine, vdr.OUT_CLS)  # writes this rank's rows of the gather buffer

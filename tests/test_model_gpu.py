@@ -162,6 +162,27 @@ def test_dinov2_giant14_geometry_swiglu_layerscale():
     _gate(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emu["dense"], gate_l2(2), gate_l2(2), "dinov2_giant14 dense")
 
 
+def test_layernorm_folding_matches_the_explicit_layernorm_path(monkeypatch):
+    """Pre-LN image models fold LayerNorm into the qkv / fc1 GEMMs (row statistics from the producer's
+    epilogue, gamma folded into the weights).  VDR_LN_FUSE=0 keeps the explicit LayerNorm kernel: both
+    paths must agree to bf16 noise, also when the token rows carry a mean several sigma away from 0
+    (variance is formed as E[x^2] - mean^2 from fp32 partial sums)."""
+    import vdr
+    cfg = SMALL["p14_d192"]
+    w = vo.make_weights(cfg, seed=12, scale=0.05)
+    w["pos_embed"] = w["pos_embed"] + 1.5          # rows with |mean| >> their spread
+    x = vo.make_images(cfg, 6, seed=13)
+    ref = vo.forward_images(cfg, w, x)
+    fused = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
+    monkeypatch.setenv("VDR_LN_FUSE", "0")
+    plain = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
+    monkeypatch.delenv("VDR_LN_FUSE")
+    g = gate_l2(cfg.layers)
+    assert _rel_l2(fused.cpu(), ref["tokens"]) <= g and _rel_l2(plain.cpu(), ref["tokens"]) <= g
+    assert _rel_l2(fused.cpu(), plain.cpu()) <= g
+    assert _min_cos(fused.cpu(), ref["tokens"]) >= 0.999
+
+
 def test_streams_and_micro_batches_do_not_change_results():
     import vdr
     cfg = SMALL["p14_d192"]
