@@ -12,6 +12,21 @@ __global__ __launch_bounds__(512) void pipe_kernel(const char* src, char* dst, i
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (mode == 32 || mode == 64) {
+    // store patterns: 32 = contiguous 1 KB per wave-instruction; 64 = "row per lane": lane l writes 16 B
+    // at row (l & 31) * 1536 B + (l >> 5) * 16 (32 rows x 32 B per instruction, as a T21 GEMM epilogue)
+    char* d = dst + (size_t)blockIdx.x * dst_bytes_per_wg;
+    const uint4 v = make_uint4(tid, tid, tid, tid);
+    for (int it = 0; it < iters; ++it) {
+      const size_t base = ((size_t)it * 8 + wave) * 49152 % (dst_bytes_per_wg - 65536);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t off = mode == 32 ? base + q * 1024 + lane * 16 : base + (size_t)(lane & 31) * 1536 + q * 32 + (lane >> 5) * 16;
+        *reinterpret_cast<uint4*>(d + off) = v;
+      }
+    }
+    return;
+  }
   if (mode == 8) {
     const char* s = src + (size_t)blockIdx.x * src_bytes_per_wg;
     for (int it = 0; it < iters; ++it) {
@@ -78,8 +93,8 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   CK(hipFuncSetAttribute((const void*)pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  const int modes[] = {1, 8, 4, 16};
-  for (int mi = 0; mi < 4; ++mi) {
+  const int modes[] = {1, 8, 4, 16, 32, 64};
+  for (int mi = 0; mi < 6; ++mi) {
     const int mode = modes[mi];
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a));
@@ -88,8 +103,9 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(b));
       float ms;
       CK(hipEventElapsedTime(&ms, a, b));
-      const double ld = mode == 8 ? (double)n_wg * iters * 8 * 8192 : mode == 16 ? (double)n_wg * iters * 4 * 16384 : (mode & 4) ? (double)n_wg * iters * 8 * 16384 : (mode & 1) ? (double)n_wg * iters * 4 * 16384 : 0, st = (mode & 2) ? (double)n_wg * iters * 4 * 4096 : 0;
-      if (rep) printf("mode %d (%s%s): %.3f ms  loads %.2f TB/s (%.1f GB/s/CU)  stores %.2f TB/s (%.1f GB/s/CU)\n", mode, mode == 8 ? "L8" : mode == 16 ? "R4" : (mode & 4) ? "R8" : (mode & 1) ? "L4" : "-", (mode & 2) ? "S" : "-", ms,
+      const double st2 = (mode == 32 || mode == 64) ? (double)n_wg * iters * 8 * 4096 : 0;
+      const double ld = mode == 8 ? (double)n_wg * iters * 8 * 8192 : mode == 16 ? (double)n_wg * iters * 4 * 16384 : (mode & 4) ? (double)n_wg * iters * 8 * 16384 : (mode & 1) ? (double)n_wg * iters * 4 * 16384 : 0, st = (mode == 32 || mode == 64) ? st2 : (mode & 2) ? (double)n_wg * iters * 4 * 4096 : 0;
+      if (rep) printf("mode %d (%s%s): %.3f ms  loads %.2f TB/s (%.1f GB/s/CU)  stores %.2f TB/s (%.1f GB/s/CU)\n", mode, mode == 32 ? "S8-contig" : mode == 64 ? "S8-rowperlane" : mode == 8 ? "L8" : mode == 16 ? "R4" : (mode & 4) ? "R8" : (mode & 1) ? "L4" : "-", (mode & 2) ? "S" : "-", ms,
                       ld / ms / 1e9, ld / ms / 1e6 / n_wg, st / ms / 1e9, st / ms / 1e6 / n_wg);
     }
   }

@@ -41,6 +41,7 @@ struct GemmK {
   const float* colsum;
   float* ln_part;
   int64_t part_stride;
+  int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
   int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
 };
@@ -737,8 +738,12 @@ VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, cha
   }
 
   if (!do_epi && acc[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
-  __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
-  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+  if (p.epi_lds) {
+    __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
+    epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+  } else {
+    epilogue_direct<EPI, TM, TN>(p, acc, m0 + wm * TM * 32, n0 + wn * TN * 32, lane);
+  }
 }
 
 
@@ -747,6 +752,85 @@ VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, cha
 // order, so the half-height tiles form the last, partial round: a tile count that leaves the final
 // round x % full costs x/2 % of a round instead of a whole one (ViT-B proj / fc2: 2.31 rounds of
 // 128 x 256 tiles -> 2 rounds + one round of 64 x 256 tiles).
+
+// Direct epilogue, no LDS: in the transposed-MFMA accumulator a row's columns 8g..8g+3 sit in lane r
+// and 8g+4..8g+7 in lane r+32.  One v_permlane32_swap per register pair (groups g, g+1) leaves lanes
+// 0-31 with the 8 consecutive columns 8g..8g+7 and lanes 32-63 with 8(g+1)..8(g+1)+7, so the whole
+// epilogue (bias, LayerNorm fold, GELU, residual, row statistics) runs on 8-column octets with 16-byte
+// global accesses.  A store wave-instruction of 32 rows x 32 B costs the CU's store path the same as
+// one of 8 rows x 128 B (measured 28.4 vs 29.3 GB/s per CU), so nothing is lost against the LDS-staged
+// form, and the LDS ring stays untouched (no barrier between the main loop and the epilogue).
+VDR_DEV void swap_halves(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+template <int EPI, int TM, int TN>
+VDR_DEV void epilogue_direct(const GemmK& p, f32x16 (&acc)[TN][TM], int64_t m_base, int n_base, int lane) {
+  static_assert(TN % 2 == 0, "column tiles are processed in pairs");
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = m_base + i * 32 + l31;
+#pragma unroll
+    for (int jp = 0; jp < TN / 2; ++jp) {
+      float s1 = 0.0f, s2 = 0.0f;
+      int64_t orow = -1;
+      if (EPI != EPI_SWIGLU) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int j = 2 * jp + jj;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            float v[8], u[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = acc[j][i][8 * gp + e], b = acc[j][i][8 * gp + 4 + e];
+              swap_halves(a, b);
+              v[e] = u[e] = a;
+              v[4 + e] = u[4 + e] = b;
+            }
+            float t1, t2;
+            orow = epi_oct<EPI>(p, v, u, m, n_base + j * 32 + 8 * (2 * gp + h), t1, t2);
+            s1 += t1;
+            s2 += t2;
+          }
+        }
+        if (p.ln_part) {
+          // this lane pair (r, r+32) covered the row's 64 columns of this block
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0 && orow >= 0 && n_base + jp * 64 < p.N) {
+            float* dst = p.ln_part + ((int64_t)((n_base + jp * 64) >> 6) * p.part_stride + orow) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
+          }
+        }
+      } else {
+        // gate pairs: tile 2jp holds x1, tile 2jp+1 the matching x2 columns
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          float v[8], u[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = acc[2 * jp][i][8 * gp + e], b = acc[2 * jp][i][8 * gp + 4 + e];
+            swap_halves(a, b);
+            v[e] = a;
+            v[4 + e] = b;
+            float c = acc[2 * jp + 1][i][8 * gp + e], d = acc[2 * jp + 1][i][8 * gp + 4 + e];
+            swap_halves(c, d);
+            u[e] = c;
+            u[4 + e] = d;
+          }
+          float t1, t2;
+          epi_oct<EPI>(p, v, u, m, n_base + 2 * jp * 32 + 8 * (2 * gp + h), t1, t2);
+        }
+      }
+    }
+  }
+}
+
 // waves per SIMD the register allocator must leave room for: 64-register accumulators (2x2 MFMA tiles
 // per wave) run 4 waves per SIMD (16 per CU) -- the per-CU load rate scales with the number of waves
 // that issue vector-memory instructions (measured: 35 GB/s with 4 waves, 75-79 GB/s with 8)
@@ -857,6 +941,14 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.part_stride = a.part_stride;
   k.abl = g_gemm_ablation;
   k.stagger = 0;
+  {
+    static int epi_lds = -1;
+    if (epi_lds < 0) {
+      const char* e = getenv("VDR_GEMM_EPI_LDS");
+      epi_lds = e && *e ? atoi(e) : 1;  // measured: the LDS-staged form is 3-20 % faster in this (non-persistent) kernel
+    }
+    k.epi_lds = epi_lds;
+  }
 
   const dim3 grid((unsigned)k.nwg), block(WAVES_M * WAVES_N * 64);
   const size_t lds_ring2 = (size_t)(BM + BN) * 64 * (PIPE - 20) > (size_t)WAVES_M * WAVES_N * 32 * 272
