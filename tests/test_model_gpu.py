@@ -177,8 +177,12 @@ def test_layernorm_folding_matches_the_explicit_layernorm_path(monkeypatch):
     monkeypatch.setenv("VDR_LN_FUSE", "0")
     plain = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
     monkeypatch.delenv("VDR_LN_FUSE")
-    g = gate_l2(cfg.layers)
-    assert _rel_l2(fused.cpu(), ref["tokens"]) <= g and _rel_l2(plain.cpu(), ref["tokens"]) <= g
+    # rows with mean 1.5 keep fewer bf16 bits for their spread: both paths sit ~1.5x above the usual gate
+    g = 1.5 * gate_l2(cfg.layers)
+    r_f, r_p = _rel_l2(fused.cpu(), ref["tokens"]), _rel_l2(plain.cpu(), ref["tokens"])
+    print(f"LN fold: fused {r_f:.3e}  explicit {r_p:.3e}  fused-vs-explicit {_rel_l2(fused.cpu(), plain.cpu()):.3e}")
+    assert r_f <= g and r_p <= g
+    assert r_f <= 1.25 * r_p, "folding LayerNorm must not cost accuracy"
     assert _rel_l2(fused.cpu(), plain.cpu()) <= g
     assert _min_cos(fused.cpu(), ref["tokens"]) >= 0.999
 

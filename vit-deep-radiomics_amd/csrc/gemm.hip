@@ -107,7 +107,8 @@ VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, i
 // epilogue is written with the widest ones).
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 template <int EPI>
-VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2) {
+VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2,
+                        float mu = 0.0f, float rs = 1.0f) {
   sum1 = 0.0f;
   sum2 = 0.0f;
   if (m >= p.M || n >= p.N) return -1;
@@ -122,7 +123,6 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   if (p.ln_stats) {
     // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
     // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
-    const float mu = p.ln_stats[2 * m], rs = p.ln_stats[2 * m + 1];
     const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.colsum + n);
     const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 4);
 #pragma unroll
@@ -231,6 +231,22 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
   constexpr int RS = 272;
   static_assert(TN % 2 == 0, "column tiles are staged in pairs");
   const int h = lane >> 5, l31 = lane & 31;
+  // LayerNorm fold: (mean, rstd) of the 4*TM rows this lane owns in the read-back phase, fetched up front
+  float st_mu[TM][4], st_rs[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      st_mu[i][rr] = 0.0f;
+      st_rs[i][rr] = 1.0f;
+      if (p.ln_stats) {
+        int64_t m = m_base + i * 32 + rr * 8 + (lane >> 3);
+        m = m < p.M ? m : p.M - 1;
+        const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
+        st_mu[i][rr] = t.x;
+        st_rs[i][rr] = t.y;
+      }
+    }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -258,7 +274,8 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
             v[4 + e] = u[4 + e] = t1[e];
           }
           float s1, s2;
-          const int64_t orow = epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2);
+          const int64_t orow = epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2,
+                                            st_mu[i][rr], st_rs[i][rr]);
           if (p.ln_part) {
             // the 8 lanes of a row hold its 64 columns of this block: (sum, sumsq) -> one slot per
             // (row, 64-column group), written exactly once: no atomics, no zeroing, deterministic
@@ -292,8 +309,15 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
             u[e] = g0[e];
             u[4 + e] = g1[e];
           }
-          float s1, s2;
-          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2);
+          float s1, s2, mu = 0.0f, rs = 1.0f;
+          if (p.ln_stats) {
+            int64_t m = m_base + i * 32 + row;
+            m = m < p.M ? m : p.M - 1;
+            const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
+            mu = t.x;
+            rs = t.y;
+          }
+          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2, mu, rs);
         }
       }
     }
@@ -773,6 +797,13 @@ VDR_DEV void epilogue_direct(const GemmK& p, f32x16 (&acc)[TN][TM], int64_t m_ba
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int64_t m = m_base + i * 32 + l31;
+    float mu = 0.0f, rs = 1.0f;
+    if (p.ln_stats) {
+      const int64_t mm = m < p.M ? m : p.M - 1;
+      const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * mm);
+      mu = t.x;
+      rs = t.y;
+    }
 #pragma unroll
     for (int jp = 0; jp < TN / 2; ++jp) {
       float s1 = 0.0f, s2 = 0.0f;
@@ -792,7 +823,7 @@ VDR_DEV void epilogue_direct(const GemmK& p, f32x16 (&acc)[TN][TM], int64_t m_ba
               v[4 + e] = u[4 + e] = b;
             }
             float t1, t2;
-            orow = epi_oct<EPI>(p, v, u, m, n_base + j * 32 + 8 * (2 * gp + h), t1, t2);
+            orow = epi_oct<EPI>(p, v, u, m, n_base + j * 32 + 8 * (2 * gp + h), t1, t2, mu, rs);
             s1 += t1;
             s2 += t2;
           }
@@ -824,7 +855,7 @@ VDR_DEV void epilogue_direct(const GemmK& p, f32x16 (&acc)[TN][TM], int64_t m_ba
             u[4 + e] = d;
           }
           float t1, t2;
-          epi_oct<EPI>(p, v, u, m, n_base + 2 * jp * 32 + 8 * (2 * gp + h), t1, t2);
+          epi_oct<EPI>(p, v, u, m, n_base + 2 * jp * 32 + 8 * (2 * gp + h), t1, t2, mu, rs);
         }
       }
     }
