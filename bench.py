@@ -108,9 +108,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libvdr has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torchrun / torch.distributed.run
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
     import vdr
     from vdr.dist import all_gather_rows
@@ -220,7 +222,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 
