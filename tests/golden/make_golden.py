@@ -178,6 +178,52 @@ def gen_dinov2_hf(tag, img, patch, dim, heads, layers, batch, wseed, xseed):
     assert err < 5e-5, err
 
 
+def gen_sam_hf(tag, img, patch, dim, heads, layers, ffn, window, global_idx, out_chans, batch, wseed, xseed):
+    """Architecture cross-check of oracle/sam_oracle.py against transformers.SamVisionModel (not the reference:
+    segment_anything is absent from /root/reference and from this container)."""
+    from transformers import SamVisionConfig, SamVisionModel
+    from oracle import sam_oracle as so
+
+    cfg = so.SamCfg(img, patch, 3, dim, heads, layers, ffn, window, tuple(global_idx), out_chans, 1e-6)
+    w = so.make_weights(cfg, seed=wseed, scale=0.05)
+    hc = SamVisionConfig(hidden_size=dim, output_channels=out_chans, num_hidden_layers=layers, num_attention_heads=heads,
+                         image_size=img, patch_size=patch, window_size=window, global_attn_indexes=list(global_idx),
+                         mlp_dim=ffn, layer_norm_eps=1e-6, use_abs_pos=True, use_rel_pos=True, qkv_bias=True,
+                         hidden_act="gelu", attention_dropout=0.0)
+    m = SamVisionModel(hc)
+    sd = m.state_dict()
+    pre = "vision_encoder."
+    sd[pre + "pos_embed"] = w["pos_embed"]
+    sd[pre + "patch_embed.projection.weight"] = w["patch_embed.proj.weight"]
+    sd[pre + "patch_embed.projection.bias"] = w["patch_embed.proj.bias"]
+    for i in range(layers):
+        s_, d = f"blocks.{i}.", pre + f"layers.{i}."
+        sd[d + "layer_norm1.weight"], sd[d + "layer_norm1.bias"] = w[s_ + "norm1.weight"], w[s_ + "norm1.bias"]
+        sd[d + "layer_norm2.weight"], sd[d + "layer_norm2.bias"] = w[s_ + "norm2.weight"], w[s_ + "norm2.bias"]
+        for k in ("qkv.weight", "qkv.bias", "proj.weight", "proj.bias", "rel_pos_h", "rel_pos_w"):
+            sd[d + "attn." + k] = w[s_ + "attn." + k]
+        sd[d + "mlp.lin1.weight"], sd[d + "mlp.lin1.bias"] = w[s_ + "mlp.fc1.weight"], w[s_ + "mlp.fc1.bias"]
+        sd[d + "mlp.lin2.weight"], sd[d + "mlp.lin2.bias"] = w[s_ + "mlp.fc2.weight"], w[s_ + "mlp.fc2.bias"]
+    sd[pre + "neck.conv1.weight"] = w["neck.0.weight"]
+    sd[pre + "neck.layer_norm1.weight"], sd[pre + "neck.layer_norm1.bias"] = w["neck.1.weight"], w["neck.1.bias"]
+    sd[pre + "neck.conv2.weight"] = w["neck.2.weight"]
+    sd[pre + "neck.layer_norm2.weight"], sd[pre + "neck.layer_norm2.bias"] = w["neck.3.weight"], w["neck.3.bias"]
+    for k, v in sd.items():
+        assert m.state_dict()[k].shape == v.shape, (k, m.state_dict()[k].shape, v.shape)
+    m.load_state_dict(sd)
+    m.eval()
+    x = so.make_images(cfg, batch, seed=xseed)
+    with torch.no_grad():
+        out = m(pixel_values=x).last_hidden_state
+    np.savez_compressed(os.path.join(HERE, f"sam_hf_{tag}.npz"), img=img, patch=patch, dim=dim, heads=heads, layers=layers,
+                        ffn=ffn, window=window, global_idx=np.array(global_idx), out_chans=out_chans, batch=batch,
+                        wseed=wseed, xseed=xseed, wscale=0.05, out=out.numpy())
+    o = so.sam_forward(cfg, w, x)
+    err = (o["out"] - out).abs().max().item()
+    print(f"sam_hf_{tag}: out {tuple(out.shape)} max|oracle-hf| = {err:.3e}")
+    assert err < 1e-4, err
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # (i) tiny, (ii) the reference's configured dims (conf/parameters_models.yaml:4,14-16),
@@ -188,3 +234,6 @@ if __name__ == "__main__":
     gen_vit_hf("tiny", 32, 8, 64, 1, 2, 128, 2, wseed=21, xseed=6)
     gen_vit_hf("p16", 64, 16, 128, 2, 3, 512, 2, wseed=22, xseed=7)
     gen_dinov2_hf("tiny", 28, 14, 64, 1, 2, 2, wseed=31, xseed=8)
+    # SAM geometry in miniature: 10x10 grid, window 4 (padded to 12 -> 9 windows), one global block
+    gen_sam_hf("tiny", 160, 16, 64, 1, 3, 128, 4, (1,), 32, 2, wseed=41, xseed=9)
+    gen_sam_hf("w7", 224, 16, 128, 2, 2, 256, 7, (1,), 64, 1, wseed=42, xseed=10)

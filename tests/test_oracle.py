@@ -85,3 +85,24 @@ def test_flops_formula_matches_survey():
     assert abs(vo.flops_per_image(vo.CONFIGS["vit_tiny16_224"]) / 1e9 - 2.51) < 0.01
     assert abs(vo.flops_per_image(vo.CONFIGS["vit_large14_336"]) / 1e9 - 381.9) < 0.2
     assert abs(vo.flops_per_image(vo.CONFIGS["dinov2_giant14_224"]) / 1e9 - 598.8) < 0.3
+
+
+@pytest.mark.parametrize("tag", ["tiny", "w7"])
+def test_sam_encoder_matches_transformers_crosscheck(golden_dir, tag):
+    """SAM / MedSAM image encoder restatement (windowed attention with zero padding after norm1,
+    decomposed relative position bias, global blocks, conv neck) vs transformers.SamVisionModel."""
+    from oracle import sam_oracle as so
+    g = _load(golden_dir, f"sam_hf_{tag}.npz")
+    cfg = so.SamCfg(int(g["img"]), int(g["patch"]), 3, int(g["dim"]), int(g["heads"]), int(g["layers"]), int(g["ffn"]),
+                    int(g["window"]), tuple(int(i) for i in g["global_idx"]), int(g["out_chans"]), 1e-6)
+    w = so.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = so.make_images(cfg, int(g["batch"]), seed=int(g["xseed"]))
+    o = so.sam_forward(cfg, w, x)
+    assert o["out"].shape == g["out"].shape
+    assert np.abs(o["out"].numpy() - g["out"]).max() <= 1e-4
+
+
+def test_sam_flops_formula():
+    from oracle import sam_oracle as so
+    # SURVEY.md §2/§8a: SAM ViT-B @ 1024^2 is ~0.94 TFLOP per slice
+    assert abs(so.flops_per_image(so.SAM_VIT_B) / 1e12 - 0.94) < 0.08

@@ -12,6 +12,18 @@ __global__ __launch_bounds__(512) void pipe_kernel(const char* src, char* dst, i
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (mode == 128) {
+    // contiguous 16-byte non-temporal stores by all 8 waves
+    char* d = dst + (size_t)blockIdx.x * dst_bytes_per_wg;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const u4 v = {(unsigned)tid, (unsigned)tid, (unsigned)tid, (unsigned)tid};
+    for (int it = 0; it < iters; ++it) {
+      const size_t base = ((size_t)it * 8 + wave) * 49152 % (dst_bytes_per_wg - 65536);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(v, reinterpret_cast<u4*>(d + base + q * 1024 + lane * 16));
+    }
+    return;
+  }
   if (mode == 32 || mode == 64) {
     // store patterns: 32 = contiguous 1 KB per wave-instruction; 64 = "row per lane": lane l writes 16 B
     // at row (l & 31) * 1536 B + (l >> 5) * 16 (32 rows x 32 B per instruction, as a T21 GEMM epilogue)
@@ -93,8 +105,8 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   CK(hipFuncSetAttribute((const void*)pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-  const int modes[] = {1, 8, 4, 16, 32, 64};
-  for (int mi = 0; mi < 6; ++mi) {
+  const int modes[] = {1, 8, 4, 16, 32, 64, 128};
+  for (int mi = 0; mi < 7; ++mi) {
     const int mode = modes[mi];
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(a));
@@ -103,9 +115,9 @@ int main(int argc, char** argv) {
       CK(hipEventSynchronize(b));
       float ms;
       CK(hipEventElapsedTime(&ms, a, b));
-      const double st2 = (mode == 32 || mode == 64) ? (double)n_wg * iters * 8 * 4096 : 0;
-      const double ld = mode == 8 ? (double)n_wg * iters * 8 * 8192 : mode == 16 ? (double)n_wg * iters * 4 * 16384 : (mode & 4) ? (double)n_wg * iters * 8 * 16384 : (mode & 1) ? (double)n_wg * iters * 4 * 16384 : 0, st = (mode == 32 || mode == 64) ? st2 : (mode & 2) ? (double)n_wg * iters * 4 * 4096 : 0;
-      if (rep) printf("mode %d (%s%s): %.3f ms  loads %.2f TB/s (%.1f GB/s/CU)  stores %.2f TB/s (%.1f GB/s/CU)\n", mode, mode == 32 ? "S8-contig" : mode == 64 ? "S8-rowperlane" : mode == 8 ? "L8" : mode == 16 ? "R4" : (mode & 4) ? "R8" : (mode & 1) ? "L4" : "-", (mode & 2) ? "S" : "-", ms,
+      const double st2 = (mode == 32 || mode == 64 || mode == 128) ? (double)n_wg * iters * 8 * 4096 : 0;
+      const double ld = mode == 8 ? (double)n_wg * iters * 8 * 8192 : mode == 16 ? (double)n_wg * iters * 4 * 16384 : (mode & 4) ? (double)n_wg * iters * 8 * 16384 : (mode & 1) ? (double)n_wg * iters * 4 * 16384 : 0, st = (mode == 32 || mode == 64 || mode == 128) ? st2 : (mode & 2) ? (double)n_wg * iters * 4 * 4096 : 0;
+      if (rep) printf("mode %d (%s%s): %.3f ms  loads %.2f TB/s (%.1f GB/s/CU)  stores %.2f TB/s (%.1f GB/s/CU)\n", mode, mode == 128 ? "S8-nt" : mode == 32 ? "S8-contig" : mode == 64 ? "S8-rowperlane" : mode == 8 ? "L8" : mode == 16 ? "R4" : (mode & 4) ? "R8" : (mode & 1) ? "L4" : "-", (mode & 2) ? "S" : "-", ms,
                       ld / ms / 1e9, ld / ms / 1e6 / n_wg, st / ms / 1e9, st / ms / 1e6 / n_wg);
     }
   }
