@@ -118,20 +118,30 @@ def main():
     from vdr.dist import all_gather_rows
     from oracle import vit_oracle as vo  # weights/images generators + cpu_baseline only
 
-    ocfg = vo.CONFIGS[a.model]
-    model = vdr.load_model(a.model, weights=vo.make_weights(ocfg, seed=1), device=dev, micro_batch=a.micro_batch, streams=a.streams)
+    sam = a.model == "medsam"
+    if sam:
+        from oracle import sam_oracle as so
+        ocfg = so.SAM_VIT_B
+        weights = so.make_weights(ocfg, seed=1)
+    else:
+        ocfg = vo.CONFIGS[a.model]
+        weights = vo.make_weights(ocfg, seed=1)
+    model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
-    images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g).to(torch.bfloat16).to(dev)  # synthetic [0,1)
+    images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g)  # synthetic [0,1)
+    images = (images if sam else images.to(torch.bfloat16)).to(dev)  # the reference feeds MedSAM fp32 slices
     total = B * world
+    if sam:  # dense descriptor maps [N, 64, 64, 256] fp32, flattened to rows for the gather
+        D = ocfg.grid * ocfg.grid * ocfg.out_chans
     feats = torch.empty((total, D), dtype=torch.float32, device=dev)  # final row-ordered [N, D] matrix
     # single GPU: the forward writes the matrix directly; multi GPU: each rank's rows go to a send buffer
     # and ONE all-gather lays them out in rank (= dataset) order
     mine = feats if world == 1 else torch.empty((B, D), dtype=torch.float32, device=dev)
 
     def step():
-        eng.forward_into(images, mine, vdr.OUT_CLS)  # writes this rank's rows of the gather buffer
+        eng.forward_into(images, mine, vdr.OUT_ENCODER if sam else vdr.OUT_CLS)  # this rank's rows of the gather buffer
         if world > 1:
             dist.all_gather_into_tensor(feats, mine)
 
@@ -178,7 +188,7 @@ def main():
     assert torch.isfinite(feats).all()
 
     if rank == 0:
-        flops_img = vo.flops_per_image(ocfg)
+        flops_img = so.flops_per_image(ocfg) if sam else vo.flops_per_image(ocfg)
         ms = dt / a.steps * 1e3
         ips = total * a.steps / dt
         kern = {}
@@ -208,18 +218,21 @@ def main():
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof_all.values()), 3)}
         out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
-               else f"images/sec, {a.model} CLS-feature extraction",
+               else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
+                     else f"images/sec, {a.model} CLS-feature extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"{a.model} {ocfg.img}^2 bf16, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32"
+               "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
+                                       f"[{total},64,64,256] fp32" if sam else
+                                       f"{a.model} {ocfg.img}^2 bf16, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32")
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "micro_batch": a.micro_batch, "streams": a.streams},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
                "roofline": roof, "kernels": kern}
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not sam:
             out["cpu_baseline"] = cpu_baseline(a.model)
         print(json.dumps(out), flush=True)
     if launched:

@@ -63,7 +63,9 @@ typedef enum {
   VDR_OUT_CLS = 0,         /* [B, D]      final-LN(x)[:,0,:]     (models_archs.py:147 contract)     */
   VDR_OUT_DENSE = 1,       /* [B, n, D]   final-LN(x)[:,1:,:]    (tfds_dense_descriptor.py:130-133) */
   VDR_OUT_PATCH_EMBED = 2, /* [B, n, D]   conv patchify only     (tfds_dense_descriptor.py:128)     */
-  VDR_OUT_TOKENS = 3       /* [B, N, D]   every token after the last block + final LN (if any)      */
+  VDR_OUT_TOKENS = 3,      /* [B, N, D]   every token after the last block + final LN (if any)      */
+  VDR_OUT_ENCODER = 4      /* [B, g, g, C] SAM neck output, channel-LAST (tfds_dense_descriptor.py:123-126   */
+                           /*             transposes the reference's [B, C, g, g] to (h, w, C) anyway)     */
 } vdr_out_mode;
 
 /* Geometry of one frozen ViT.  Mirrors the constructor arguments the reference
@@ -91,7 +93,11 @@ typedef struct {
   int32_t streams;    /* internal HIP streams the micro-batches are spread over (0/1 = the caller's   */
                       /* stream only); >1 lets kernels of independent micro-batches overlap, e.g. one */
                       /* GEMM's store-bound epilogue under another's MFMA main loop                   */
-  int32_t reserved[3];
+  /* SAM / MedSAM image encoder (segment_anything ImageEncoderViT, tfds_dense_descriptor.py:104,123):   */
+  int32_t window;     /* > 0: windowed attention of this side (14) with decomposed relative position   */
+                      /* bias in every block; needs has_cls = 0, has_pos = 1, pre_ln = 1               */
+  int32_t global_mask;/* bit i set: block i attends over the whole grid (SAM ViT-B: 2,5,8,11 = 0x924)  */
+  int32_t neck_chans; /* output channels of the conv neck (256); 1x1 conv, LN2d, 3x3 conv, LN2d        */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;
@@ -182,6 +188,15 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
  *   out [batch*seq, H*64] bf16;  softmax(q k^T / 8) v per (batch, head), no mask. */
 int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
                      void* stream);
+
+/* SAM / MedSAM Attention.forward with use_rel_pos (third-party segment_anything ImageEncoderViT, called at
+ * tfds_dense_descriptor.py:123): per (window, head) softmax(q k^T dh^-0.5 + q.Rh[qh-kh] + q.Rw[qw-kw]) v.
+ *   qkv   [batch*S*S, 3*H*64] bf16, `batch` windows (or whole grids) of S x S tokens, row-major (h, w)
+ *   rel_pos_h / rel_pos_w  fp32 [2S-1, 64] (the block's parameters)
+ *   rel   device scratch, fp32 [batch*S*S*H*2S]
+ *   out   [batch*S*S, H*64] bf16.   S in {4, 7, 10, 14} (one pass) or 64 (online softmax). */
+int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float* rel_pos_w, float* rel, void* out,
+                            int batch, int S, int heads, void* stream);
 
 /* nn.Conv2d(in_chans, D, kernel=p, stride=p) + flatten(2).transpose(1,2) — DINOv2 PatchEmbed,
  * the op called at tfds_dense_descriptor.py:128.

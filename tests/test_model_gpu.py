@@ -300,3 +300,79 @@ def test_full_batch_properties_at_baseline_size():
     assert torch.equal(out_p, out[perm])
     small = e.forward(x[100:103], vdr.OUT_CLS)
     assert torch.equal(small, out[100:103])
+
+
+# ---- SAM / MedSAM image encoder (the reference's default backbone) ----------------
+def _sam_engine(cfg, w):
+    import vdr
+    vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=3, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
+                       mlp_hidden=cfg.mlp_hidden, has_cls=False, has_pos=True, ln_eps=cfg.ln_eps, window=cfg.window,
+                       global_blocks=tuple(cfg.global_idx), neck_chans=cfg.out_chans)
+    e = vdr.Engine(vc)
+    e.load_weights(w)
+    return e
+
+
+@pytest.mark.parametrize("name,cfgargs,batch", [
+    ("grid10_win4_padded", dict(img=160, patch=16, dim=64, heads=1, layers=3, mlp_hidden=128, window=4, global_idx=(1,), out_chans=64), 3),
+    ("grid14_win7", dict(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64), 2),
+    ("grid14_win4_allwindow", dict(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=4, global_idx=(), out_chans=128), 2),
+])
+def test_sam_encoder_small(name, cfgargs, batch):
+    import vdr
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(**cfgargs)
+    w = so.make_weights(cfg, seed=21, scale=0.05)
+    x = so.make_images(cfg, batch, seed=22)
+    ref = so.sam_forward(cfg, w, x)
+    emu = so.sam_forward(cfg, w, x, emulate_bf16=True)
+    e = _sam_engine(cfg, w)
+    tok = e.forward(x.cuda(), vdr.OUT_TOKENS)
+    g = cfg.grid
+    _gate(tok, ref["tokens"].reshape(batch, g * g, cfg.dim), emu["tokens"].reshape(batch, g * g, cfg.dim),
+          gate_l2(cfg.layers), gate_l2(cfg.layers), f"sam {name} tokens")
+    out = e.forward(x.cuda(), vdr.OUT_ENCODER)  # [B, g, g, C] channel-last
+    assert out.shape == (batch, g, g, cfg.out_chans)
+    _gate(out, ref["out"].permute(0, 2, 3, 1), emu["out"].permute(0, 2, 3, 1), gate_l2(cfg.layers) + 4e-3,
+          gate_l2(cfg.layers) + 4e-3, f"sam {name} neck output")
+
+
+def test_sam_golden_transformers_crosscheck(golden_dir):
+    import vdr
+    from oracle import sam_oracle as so
+    g = np.load(os.path.join(golden_dir, "sam_hf_w7.npz"), allow_pickle=False)
+    cfg = so.SamCfg(int(g["img"]), int(g["patch"]), 3, int(g["dim"]), int(g["heads"]), int(g["layers"]), int(g["ffn"]),
+                    int(g["window"]), tuple(int(i) for i in g["global_idx"]), int(g["out_chans"]), 1e-6)
+    w = so.make_weights(cfg, seed=int(g["wseed"]), scale=float(g["wscale"]))
+    x = so.make_images(cfg, int(g["batch"]), seed=int(g["xseed"]))
+    out = _sam_engine(cfg, w).forward(x.cuda(), vdr.OUT_ENCODER).permute(0, 3, 1, 2)
+    want = torch.from_numpy(g["out"])
+    assert _rel_l2(out.cpu(), want) <= gate_l2(cfg.layers) + 4e-3
+    assert _min_cos(out.cpu().permute(0, 2, 3, 1), want.permute(0, 2, 3, 1)) >= 0.999
+
+
+def test_medsam_vit_b_1024_geometry_and_boundary():
+    """The reference's default path (tfds_dense_descriptor.py:93-126): load_model('medsam', path) ->
+    model.image_encoder(x[1,3,1024,1024]) -> [1,256,64,64] -> (64,64,256) numpy.  Full SAM ViT-B geometry
+    (768/12 heads, window 14 -> 25 zero-padded windows, global attention over 4096 tokens) with the depth cut
+    to 3 blocks (window, window, global) so the CPU oracle stays in seconds."""
+    import vdr
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(layers=3, global_idx=(2,))
+    w = so.make_weights(cfg, seed=23)
+    x = so.make_images(cfg, 1, seed=24)
+    ref = so.sam_forward(cfg, w, x)
+    vc = vdr.VdrConfig(**{**vdr.ARCHS["medsam"].__dict__, "layers": 3, "global_blocks": (2,)})
+    model = vdr.VitDescriptorModel(vc, w, "medsam")
+    enc = model.image_encoder(x.cuda())
+    assert enc.shape == (1, 256, 64, 64)
+    assert _rel_l2(enc.cpu(), ref["out"]) <= gate_l2(3) + 4e-3
+    assert _min_cos(enc.cpu().permute(0, 2, 3, 1), ref["out"].permute(0, 2, 3, 1)) >= 0.999
+    f = vdr.get_dense_descriptor(model, x[0].numpy())
+    assert f.shape == (64, 64, 256) and f.dtype == np.float32
+    np.testing.assert_array_equal(f, np.transpose(enc[0].cpu().numpy(), (1, 2, 0)))
+    # segment_anything checkpoint key names are accepted as they are
+    from vdr.model import from_sam_state_dict
+    sam_sd = {("image_encoder." + k).replace(".mlp.fc1.", ".mlp.lin1.").replace(".mlp.fc2.", ".mlp.lin2."): v for k, v in w.items()}
+    sam_sd["prompt_encoder.dummy"] = torch.zeros(1)
+    assert sorted(from_sam_state_dict(sam_sd)) == sorted(w)

@@ -252,3 +252,41 @@ def test_patch_embed(ops, img, p, D, dt):
     y2 = y2.float().cpu().reshape(B, n + 1, D)
     assert torch.equal(y2[:, 0], torch.zeros(B, D))
     _assert_close(y2[:, 1:].reshape(B * n, D), ref + pos[1:].repeat(B, 1), BF16_EPS, 2e-3, "patch_embed+pos")
+
+
+# ---- SAM / MedSAM attention with decomposed relative position bias ------------------------------------
+def _relpos_attn_ref(qkv, rel_h, rel_w, B, S, H):
+    from oracle import sam_oracle as so
+    q, k, v = qkv.float().reshape(B, S * S, 3, H, 64).permute(2, 0, 3, 1, 4)
+    attn = (q * 0.125) @ k.transpose(-1, -2)
+    Rh, Rw = so.rel_table(S, rel_h), so.rel_table(S, rel_w)
+    rq = q.reshape(B, H, S, S, 64)
+    rh = torch.einsum("bnhwc,hkc->bnhwk", rq, Rh)
+    rw = torch.einsum("bnhwc,wkc->bnhwk", rq, Rw)
+    attn = (attn.view(B, H, S, S, S, S) + rh[..., :, None] + rw[..., None, :]).view(B, H, S * S, S * S)
+    o = torch.softmax(attn, dim=-1) @ v
+    return o.transpose(1, 2).reshape(B * S * S, H * 64)
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 4, 2), (5, 7, 1), (2, 10, 2), (4, 14, 3), (25, 14, 12)])
+def test_attention_relpos_windows(ops, B, S, H):
+    g = torch.Generator().manual_seed(S * 100 + B)
+    qkv = _bf(torch.randn(B * S * S, 3 * H * 64, generator=g))
+    rel_h = torch.randn(2 * S - 1, 64, generator=g) * 0.1
+    rel_w = torch.randn(2 * S - 1, 64, generator=g) * 0.1
+    ref = _relpos_attn_ref(qkv, rel_h, rel_w, B, S, H)
+    out = ops.attention_relpos(qkv.cuda(), rel_h.cuda(), rel_w.cuda(), B, S, H)
+    _assert_close(out, ref, 2 * BF16_EPS, 6e-3, f"relpos attention B{B} S{S} H{H}")
+
+
+def test_attention_relpos_global_grid_64(ops):
+    """The four global blocks of SAM ViT-B: 64 x 64 = 4096 tokens, online softmax over 128-key chunks
+    (two grid rows per chunk) with the bias indexed from registers."""
+    B, S, H = 1, 64, 2
+    g = torch.Generator().manual_seed(64)
+    qkv = _bf(torch.randn(B * S * S, 3 * H * 64, generator=g))
+    rel_h = torch.randn(2 * S - 1, 64, generator=g) * 0.1
+    rel_w = torch.randn(2 * S - 1, 64, generator=g) * 0.1
+    ref = _relpos_attn_ref(qkv, rel_h, rel_w, B, S, H)
+    out = ops.attention_relpos(qkv.cuda(), rel_h.cuda(), rel_w.cuda(), B, S, H)
+    _assert_close(out, ref, 2 * BF16_EPS, 6e-3, "relpos attention global 64x64")

@@ -1,0 +1,347 @@
+// Attention with decomposed relative position bias for the SAM / MedSAM image encoder (the backbone the
+// reference loads by default: src/tfds_dense_descriptor.py:93-107, called at :123).
+//
+//   attn[q, k] = (q . k) * dh^-0.5 + q . Rh[qh - kh] + q . Rw[qw - kw]      (third-party ImageEncoderViT,
+//   softmax over k, times v                                                   add_decomposed_rel_pos)
+//
+// for S x S token grids: the 14 x 14 windows (196 tokens, zero-padded border windows included) and the
+// four global blocks over the whole 64 x 64 grid (4096 tokens).
+//
+// relpos_kernel   : rel[token][head][0..S) = q . Rh[qh - kh + S-1],  rel[...][S..2S) = q . Rw[qw - kw + S-1]
+//                   (fp32; 2S dot products of length 64 per token and head)
+// attn_relpos_kernel<NT, S, MULTI>: the fused attention of attention.hip (K in swizzled LDS, V^T in LDS,
+//                   S^T = K.Q^T so a softmax row is lane-local, P fed back as an MFMA operand) with the bias
+//                   added to the logits from registers: the key of accumulator element (t, e, half) is a
+//                   compile-time constant, so kh = key / S and kw = key % S index register arrays statically.
+//                   MULTI (S = 64): online softmax over 128-key chunks = two grid rows per chunk.
+#include "vdr_dev.h"
+#include "vdr_kernels.h"
+
+namespace vdr {
+
+// ---------------------------------------------------------------------------------------------------
+// rel-pos pre-pass: one wave per (token, head); lane j < 2S owns output j
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                     const float* __restrict__ rel_w, float* __restrict__ rel,
+                                                     int64_t tokens, int seq, int S, int heads) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // token * heads + head
+  if (item >= tokens * heads) return;
+  const int64_t tok = item / heads;
+  const int hd = (int)(item - tok * heads);
+  const int pos = (int)(tok % seq);  // position inside the window / grid
+  const int qh = pos / S, qw = pos - qh * S;
+  const bf16_t* q = qkv + tok * (int64_t)(3 * heads * 64) + hd * 64;
+  const float qv = (float)q[lane];  // lane c holds q[c]
+  float* dst = rel + item * (int64_t)(2 * S);
+  for (int j0 = 0; j0 < 2 * S; j0 += 64) {
+    const int j = j0 + lane;
+    const bool act = j < 2 * S;
+    const int jj = act ? j : 0;
+    const bool is_h = jj < S;
+    const int kk = is_h ? jj : jj - S;
+    const float* row = (is_h ? rel_h + (int64_t)(qh - kk + S - 1) * 64 : rel_w + (int64_t)(qw - kk + S - 1) * 64);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) acc = fmaf(__shfl(qv, c, 64), row[c], acc);
+    if (act) dst[j] = acc;
+  }
+}
+
+hipError_t launch_relpos(const void* qkv, const float* rel_h, const float* rel_w, float* rel, int64_t tokens, int seq,
+                         int S, int heads, hipStream_t s) {
+  if (tokens <= 0 || S <= 0 || S * S != seq) return hipErrorInvalidValue;
+  const int64_t items = tokens * heads;
+  hipLaunchKernelGGL(relpos_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, (const bf16_t*)qkv, rel_h, rel_w,
+                     rel, tokens, seq, S, heads);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct AttnRK {
+  const bf16_t* qkv;
+  const float* rel;  // [batch*seq][heads][2S]
+  bf16_t* out;
+  int seq, heads;
+  int64_t ld_qkv, ld_out;
+  int qt_per_block;
+  int n_chunks;
+};
+
+template <int NT, int S, bool MULTI>
+__global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
+  constexpr int KEYS = NT * 32;
+  constexpr int VT_STRIDE = NT * 64 + 8;
+  static_assert(!MULTI || (S == 64 && NT == 4), "the chunked form assumes 128-key chunks = two rows of a 64-wide grid");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sVt = smem + KEYS * 128;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5;
+  const int l31 = lane & 31;
+  const int swz = (lane >> 1) & 7;
+
+  const int b = blockIdx.x / p.heads;
+  const int hd = blockIdx.x - b * p.heads;
+  const int HD = p.heads * 64;
+  const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
+  const bf16_t* kb = qb + HD;
+  const bf16_t* vb = qb + 2 * HD;
+  bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
+
+  const int nqt = (p.seq + 31) >> 5;
+  const int qt_begin = blockIdx.y * p.qt_per_block;
+  const int qt_end = min(nqt, qt_begin + p.qt_per_block);
+  constexpr float LOG2E = 1.44269504088896341f;
+
+  f32x16 o[2];
+  float m_run = -INFINITY, l_run = 0.0f;
+  bf16x8 qf[4];
+  constexpr int NRW = S;                 // rel_w values kept in registers
+  constexpr int NRH = MULTI ? 2 : S;     // rel_h values: the whole column, or the chunk's two grid rows
+  float relw[NRW], relh[NRH];
+  const float* relrow = nullptr;
+
+  auto load_q = [&](int qt) {
+    int q = qt * 32 + l31;
+    q = q < p.seq ? q : p.seq - 1;
+    const bf16_t* src = qb + (int64_t)q * p.ld_qkv + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
+    relrow = p.rel + (((int64_t)b * p.seq + q) * p.heads + hd) * (2 * S);
+#pragma unroll
+    for (int j = 0; j < NRW; ++j) relw[j] = relrow[S + j];
+    if (!MULTI) {
+#pragma unroll
+      for (int j = 0; j < NRH; ++j) relh[j] = relrow[j];
+    }
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
+    m_run = -INFINITY;
+    l_run = 0.0f;
+  };
+
+  auto stage = [&](int kc0) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int piece = wave * NT + q;
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int key = kc0 + r;
+      key = key < p.seq ? key : p.seq - 1;
+      glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
+    }
+    constexpr int NIT = (NT * 128 + 255) / 256;
+    bf16x8 v0[NIT], v1[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
+      const int dc = (it >> 3) & 7;
+      const int kp = (it & 7) | ((it >> 6) << 3);
+      const int key0 = kc0 + 2 * kp;
+      const int k0 = key0 < p.seq ? key0 : p.seq - 1;
+      const int k1 = key0 + 1 < p.seq ? key0 + 1 : p.seq - 1;
+      v0[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k0 * p.ld_qkv + dc * 8);
+      v1[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k1 * p.ld_qkv + dc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int it = tid + i * 256;
+      if (it < NT * 128) {
+        const int dc = (it >> 3) & 7;
+        const int kp = (it & 7) | ((it >> 6) << 3);
+        const int key0 = kc0 + 2 * kp;
+        const bool ok0 = key0 < p.seq, ok1 = key0 + 1 < p.seq;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16x2 pr;
+          pr[0] = ok0 ? v0[i][e] : (bf16_t)0.0f;
+          pr[1] = ok1 ? v1[i][e] : (bf16_t)0.0f;
+          *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  auto process = [&](int kc0, bool rescale) {
+    if (MULTI) {
+      // this chunk covers grid rows kc0/64 and kc0/64 + 1
+      relh[0] = relrow[kc0 >> 6];
+      relh[1] = relrow[min((kc0 >> 6) + 1, S - 1)];
+    }
+    f32x16 s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf =
+            *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * ks + hh) ^ swz) * 16));
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // logits = s * dh^-0.5 + rel_h[kh] + rel_w[kw]; the (chunk-local) key of element (t, e, half) is static
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int k0 = t * 32 + (e & 3) + 8 * (e >> 2);  // half 0; half 1 is k0 + 4
+        const int k1 = k0 + 4;
+        const int kh0 = MULTI ? (k0 >> 6) : (k0 / S < S ? k0 / S : S - 1);
+        const int kh1 = MULTI ? (k1 >> 6) : (k1 / S < S ? k1 / S : S - 1);
+        const int kw0 = MULTI ? (k0 & 63) : k0 % S;
+        const int kw1 = MULTI ? (k1 & 63) : k1 % S;
+        const float b0 = relh[kh0] + relw[kw0];
+        const float b1 = relh[kh1] + relw[kw1];
+        const float bias = hh ? b1 : b0;
+        float l = fmaf(s[t][e], 0.125f, bias);
+        const int key = kc0 + k0 + 4 * hh;
+        if (kc0 + t * 32 + 32 > p.seq) l = key >= p.seq ? -INFINITY : l;
+        s[t][e] = l;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (rescale) {
+      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+      l_run *= alpha;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[nd][e] *= alpha;
+    }
+    m_run = m_new;
+    const float mb = m_new * LOG2E;
+    float lsum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], LOG2E, -mb));
+          lsum += pv;
+          pf[j] = (bf16_t)pv;
+        }
+        const int koff = (t * 32 + s2 * 16 + 4 * hh) * 2;
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd) {
+          const char* vrow = sVt + (nd * 32 + l31) * VT_STRIDE + koff;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+          bf16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = lo[j];
+            vf[4 + j] = hi[j];
+          }
+          o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    l_run += lsum;
+  };
+
+  auto store = [&](int qt) {
+    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = qt * 32 + l31;
+    if (q < p.seq) {
+      bf16_t* dst = ob + (int64_t)q * p.ld_out;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
+          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
+        }
+    }
+  };
+
+  if (!MULTI) {
+    stage(0);
+    for (int qt = qt_begin + wave; qt < qt_end; qt += 4) {
+      load_q(qt);
+      process(0, false);
+      store(qt);
+    }
+  } else {
+    const int qt = qt_begin + wave;
+    const bool valid = qt < qt_end;
+    load_q(valid ? qt : qt_begin);
+    for (int c = 0; c < p.n_chunks; ++c) {
+      if (c) __syncthreads();
+      stage(c * KEYS);
+      if (valid) process(c * KEYS, c > 0);
+    }
+    if (valid) store(qt);
+  }
+}
+
+template <int NT, int S, bool MULTI>
+static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
+  constexpr size_t lds = (size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8);
+  auto fn = attn_relpos_kernel<NT, S, MULTI>;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int nqt = (k.seq + 31) / 32;
+  const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention_relpos(const void* qkv, const float* rel, void* out, int batch, int S, int heads,
+                                   hipStream_t s) {
+  if (batch <= 0 || S <= 0 || heads <= 0) return hipErrorInvalidValue;
+  AttnRK k;
+  k.qkv = (const bf16_t*)qkv;
+  k.rel = rel;
+  k.out = (bf16_t*)out;
+  k.seq = S * S;
+  k.heads = heads;
+  k.ld_qkv = (int64_t)3 * heads * 64;
+  k.ld_out = (int64_t)heads * 64;
+  const int nqt = (k.seq + 31) / 32;
+  k.qt_per_block = nqt;
+  k.n_chunks = 1;
+  switch (S) {
+    case 4:
+      return launch_rp<2, 4, false>(k, batch, s);
+    case 7:
+      return launch_rp<2, 7, false>(k, batch, s);
+    case 10:
+      return launch_rp<4, 10, false>(k, batch, s);
+    case 14:
+      return launch_rp<7, 14, false>(k, batch, s);
+    case 64:
+      k.qt_per_block = 4;
+      k.n_chunks = (k.seq + 127) / 128;
+      return launch_rp<4, 64, true>(k, batch, s);
+    default:
+      return hipErrorInvalidValue;  // grid sides outside {4, 7, 10, 14, 64} are not instantiated
+  }
+}
+
+}  // namespace vdr

@@ -41,6 +41,7 @@ struct GemmK {
   const float* colsum;
   float* ln_part;
   int64_t part_stride;
+  int win_ws, win_g;  // SAM window un-partition of the output rows (0 = off)
   int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
   int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
@@ -119,6 +120,19 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     const int i = (int)(m - g * p.rpg);
     orow = g * p.gstride + p.off + i;
     prow = p.off + i;
+  }
+  if (p.win_ws > 0) {
+    // window un-partition (segment_anything window_unpartition): row m of the windowed order -> token (y, x)
+    const int ws = p.win_ws, g = p.win_g, nw = (g + ws - 1) / ws;
+    const int64_t widx = m / (ws * ws);
+    const int wtok = (int)(m - widx * (ws * ws));
+    const int wx = (int)(widx % nw);
+    const int64_t t2 = widx / nw;
+    const int wy = (int)(t2 % nw);
+    const int64_t b = t2 / nw;
+    const int y = wy * ws + wtok / ws, x = wx * ws + wtok % ws;
+    if (y >= g || x >= g) return -1;  // zero padding of the border windows: dropped
+    orow = (b * g + y) * g + x;
   }
   if (p.ln_stats) {
     // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
@@ -966,6 +980,8 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
       }
     }
   }
+  k.win_ws = a.win_ws;
+  k.win_g = a.win_g;
   k.ln_stats = a.ln_stats;
   k.colsum = a.colsum;
   k.ln_part = a.ln_part;
@@ -1017,7 +1033,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
   g_gemm_ablation = variant / 100;
   variant %= 100;
-  if ((a.ln_stats || a.ln_part) && variant < 12) return hipErrorInvalidValue;  // needs epilogue_lds (ring2)
+  if ((a.ln_stats || a.ln_part || a.win_ws) && variant < 12) return hipErrorInvalidValue;  // needs epilogue_lds (ring2)
   if (a.ln_part && (a.N & 63)) return hipErrorInvalidValue;
   switch (variant) {
     case 0:

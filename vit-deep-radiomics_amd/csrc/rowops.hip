@@ -28,6 +28,7 @@ struct LnK {
   int64_t ogs;
   int ooff;
   int cls_period;
+  int win_ws, win_g;
 };
 
 VDR_DEV int64_t map_row(int64_t r, int rpg, int64_t gs, int off) {
@@ -42,7 +43,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnK p) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= p.rows) return;
   const int64_t ir = map_row(r, p.irpg, p.igs, p.ioff);
-  const int64_t orow = map_row(r, p.orpg, p.ogs, p.ooff);
+  int64_t orow = map_row(r, p.orpg, p.ogs, p.ooff);
+  if (p.win_ws > 0) {
+    // window partition (segment_anything window_partition): token (b, y, x) -> window-major order
+    const int g = p.win_g, ws = p.win_ws, nw = (g + ws - 1) / ws;
+    const int64_t b = r / (g * g);
+    const int rem = (int)(r - b * g * g);
+    const int y = rem / g, x = rem - y * g;
+    orow = ((b * nw + y / ws) * nw + x / ws) * (int64_t)(ws * ws) + (y % ws) * ws + (x % ws);
+  }
   const bool from_cls = p.cls != nullptr && (r % p.cls_period) == 0;
   float v[NP][4];
   float sum = 0.0f;
@@ -144,6 +153,8 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
   k.ogs = a.omap.gstride;
   k.ooff = a.omap.off;
   k.cls_period = a.cls_period > 0 ? a.cls_period : 1;
+  k.win_ws = a.win_ws;
+  k.win_g = a.win_g;
   if (a.in_bf16) return a.out_bf16 ? ln_dispatch<true, true>(k, s) : ln_dispatch<true, false>(k, s);
   return a.out_bf16 ? ln_dispatch<false, true>(k, s) : ln_dispatch<false, false>(k, s);
 }
@@ -385,6 +396,34 @@ hipError_t launch_cls_rows_stats(const float* cls, const float* pos, void* x, fl
   const int groups = D / 64;
   hipLaunchKernelGGL(cls_rows_stats_kernel, dim3((unsigned)(batch * groups)), dim3(64), 0, s, cls, pos, (bf16_t*)x, part,
                      part_stride, groups, row_stride, D);
+  return hipGetLastError();
+}
+
+// 3x3 / pad 1 im2col over NHWC tokens (the SAM neck's second conv): one thread moves 8 channels (16 B)
+__global__ __launch_bounds__(256) void im2col3_kernel(const bf16_t* __restrict__ y, bf16_t* __restrict__ col,
+                                                      int64_t total, int g, int C) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = C >> 3;
+  const int64_t row = idx / (9 * c8);
+  const int rem = (int)(idx - row * 9 * c8);
+  const int j = rem / c8, c = (rem - j * c8) * 8;
+  const int ky = j / 3, kx = j - ky * 3;
+  const int64_t b = row / (g * g);
+  const int pix = (int)(row - b * g * g);
+  const int py = pix / g + ky - 1, px = pix % g + kx - 1;
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
+  if (py >= 0 && py < g && px >= 0 && px < g) v = *reinterpret_cast<const bf16x8*>(y + ((b * g + py) * g + px) * (int64_t)C + c);
+  *reinterpret_cast<bf16x8*>(col + row * (int64_t)(9 * C) + j * C + c) = v;
+}
+
+hipError_t launch_im2col3(const void* y, void* col, int batch, int g, int C, hipStream_t s) {
+  if (C & 7) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)batch * g * g * 9 * (C / 8);
+  hipLaunchKernelGGL(im2col3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const bf16_t*)y, (bf16_t*)col,
+                     total, g, C);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ uint16_t f32_to_bf16(float f) {
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-enum WKind { W_VEC_F32, W_MAT_BF16, W_PATCH_BF16, W_W12_BF16, W_W12_BIAS };
+enum WKind { W_VEC_F32, W_MAT_BF16, W_PATCH_BF16, W_W12_BF16, W_W12_BIAS, W_CONV3_BF16 };
 
 struct WSlot {
   std::string name;
@@ -47,6 +47,7 @@ struct LayerW {
   const void *wqkv, *wproj, *w1, *w2;
   // LayerNorm folded into the consuming GEMM (pre-LN image models): W' = W.diag(gamma) in bf16,
   // colsum[n] = sum_k W'[n][k], tbias[n] = sum_k beta[k] W[n][k] + b[n]
+  const float *relh = nullptr, *relw = nullptr;  // SAM decomposed relative position tables
   void *wqkv_f = nullptr, *w1_f = nullptr;
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
@@ -66,6 +67,8 @@ struct vdr_model {
   std::map<std::string, int> index;
   std::vector<LayerW> layers;
   const void* w_patch = nullptr;
+  const void *w_neck0 = nullptr, *w_neck2 = nullptr;
+  const float *neck1w = nullptr, *neck1b = nullptr, *neck3w = nullptr, *neck3b = nullptr;
   const float *b_patch = nullptr, *cls = nullptr, *pos = nullptr, *normw = nullptr, *normb = nullptr,
               *inw = nullptr, *inb = nullptr;
   bool resolved = false;
@@ -133,6 +136,11 @@ void build_slots(vdr_model* m) {
     add_slot(m, p + "norm1.bias", W_VEC_F32, 1, D);
     add_slot(m, p + "attn.qkv.weight", W_MAT_BF16, 3 * D, D);
     add_slot(m, p + "attn.qkv.bias", W_VEC_F32, 1, 3 * D);
+    if (c.window > 0) {
+      const int size = ((c.global_mask >> i) & 1) ? c.img / c.patch : c.window;
+      add_slot(m, p + "attn.rel_pos_h", W_VEC_F32, 2 * size - 1, 64);
+      add_slot(m, p + "attn.rel_pos_w", W_VEC_F32, 2 * size - 1, 64);
+    }
     add_slot(m, p + "attn.proj.weight", W_MAT_BF16, D, D);
     add_slot(m, p + "attn.proj.bias", W_VEC_F32, 1, D);
     if (c.layerscale) add_slot(m, p + "ls1.gamma", W_VEC_F32, 1, D);
@@ -151,9 +159,18 @@ void build_slots(vdr_model* m) {
     }
     if (c.layerscale) add_slot(m, p + "ls2.gamma", W_VEC_F32, 1, D);
   }
-  if (c.pre_ln) {
+  if (c.pre_ln && c.window == 0) {
     add_slot(m, "norm.weight", W_VEC_F32, 1, D);
     add_slot(m, "norm.bias", W_VEC_F32, 1, D);
+  }
+  if (c.window > 0) {
+    const int C = c.neck_chans;
+    add_slot(m, "neck.0.weight", W_MAT_BF16, C, D);
+    add_slot(m, "neck.1.weight", W_VEC_F32, 1, C);
+    add_slot(m, "neck.1.bias", W_VEC_F32, 1, C);
+    add_slot(m, "neck.2.weight", W_CONV3_BF16, C, (int64_t)C * 9);
+    add_slot(m, "neck.3.weight", W_VEC_F32, 1, C);
+    add_slot(m, "neck.3.bias", W_VEC_F32, 1, C);
   }
 }
 
@@ -225,6 +242,12 @@ int resolve(vdr_model* m) {
   m->inb = (const float*)dev_of(m, "input_norm.bias");
   m->normw = (const float*)dev_of(m, "norm.weight");
   m->normb = (const float*)dev_of(m, "norm.bias");
+  m->w_neck0 = dev_of(m, "neck.0.weight");
+  m->w_neck2 = dev_of(m, "neck.2.weight");
+  m->neck1w = (const float*)dev_of(m, "neck.1.weight");
+  m->neck1b = (const float*)dev_of(m, "neck.1.bias");
+  m->neck3w = (const float*)dev_of(m, "neck.3.weight");
+  m->neck3b = (const float*)dev_of(m, "neck.3.bias");
   m->layers.resize(c.layers);
   for (int i = 0; i < c.layers; ++i) {
     const std::string p = "blocks." + std::to_string(i) + ".";
@@ -237,6 +260,8 @@ int resolve(vdr_model* m) {
     L.bqkv = (const float*)dev_of(m, p + "attn.qkv.bias");
     L.wproj = dev_of(m, p + "attn.proj.weight");
     L.bproj = (const float*)dev_of(m, p + "attn.proj.bias");
+    L.relh = (const float*)dev_of(m, p + "attn.rel_pos_h");
+    L.relw = (const float*)dev_of(m, p + "attn.rel_pos_w");
     L.ls1 = (const float*)dev_of(m, p + "ls1.gamma");
     L.ls2 = (const float*)dev_of(m, p + "ls2.gamma");
     if (c.act == VDR_ACT_SWIGLU) {
@@ -284,6 +309,8 @@ int resolve(vdr_model* m) {
 // ---- workspace carving ------------------------------------------------------------------------
 struct Carve {
   char *x, *h, *qkv, *o, *u;
+  char* hg = nullptr;    // SAM: LN1 output of the global blocks (h holds the windowed, zero-padded order)
+  float* rel = nullptr;  // SAM: relative position terms [tokens][heads][2S]
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;
   size_t total;
@@ -291,7 +318,16 @@ struct Carve {
 
 Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
   const vdr_config& c = m->cfg;
-  const size_t Mp = (size_t)round_up(mb * ntok, 256) + 256;
+  size_t rows = (size_t)mb * ntok;
+  size_t rel_floats = 0;
+  if (c.window > 0) {
+    const size_t g = c.img / c.patch, ws = c.window, nw = (g + ws - 1) / ws;
+    const size_t wtok = nw * nw * ws * ws;
+    if (wtok > (size_t)ntok) rows = (size_t)mb * wtok;
+    const size_t rw = (size_t)mb * wtok * c.heads * 2 * ws, rg = (size_t)mb * ntok * c.heads * 2 * g;
+    rel_floats = rw > rg ? rw : rg;
+  }
+  const size_t Mp = (size_t)round_up((int)rows, 256) + 256;
   const size_t D = c.dim, F = c.mlp_hidden;
   size_t off = 0;
   Carve w;
@@ -309,7 +345,15 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
     const size_t colb = (size_t)mb * m->n_patches * m->Kp * 2 + 4096;
     if (colb > ub) ub = colb;
   }
+  if (c.window > 0) {
+    const size_t col3 = (size_t)mb * ntok * 9 * c.neck_chans * 2 + 4096;
+    if (col3 > ub) ub = col3;
+  }
   w.u = take(ub);
+  if (c.window > 0) {
+    w.hg = take(Mp * D * 2);
+    w.rel = (float*)take(rel_floats * 4 + 256);
+  }
   w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
   w.stats = (float*)take(Mp * 8);
   w.Mp = (int64_t)Mp;
@@ -439,7 +483,7 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
 
 int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, void* y, int out_bf16,
               const float* gw, const float* gb, int64_t rows, RowMap imap, const float* clsrc = nullptr,
-              int cls_period = 0) {
+              int cls_period = 0, int width = 0) {
   LnArgs a{};
   a.x = x;
   a.in_bf16 = in_bf16;
@@ -448,7 +492,7 @@ int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, 
   a.gamma = gw;
   a.beta = gb;
   a.rows = rows;
-  a.D = m->cfg.dim;
+  a.D = width ? width : m->cfg.dim;
   a.eps = m->cfg.ln_eps;
   a.imap = imap;
   a.omap = identity_map();
@@ -537,6 +581,109 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
   return VDR_OK;
 }
 
+// SAM / MedSAM ImageEncoderViT blocks + neck over x [mb * g*g rows] (tokens NHWC, pos_embed already added).
+// Window blocks: LN1 writes the window-partitioned, zero-padded order (padding rows of w.h stay zero),
+// qkv / rel-pos / attention run on windows, the proj epilogue un-partitions while adding the residual.
+int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, char* out, bool tokens_only) {
+  const vdr_config& c = m->cfg;
+  const int D = c.dim, F = c.mlp_hidden, H = c.heads, C = c.neck_chans;
+  const int g = c.img / c.patch, n = g * g, ws = c.window, nw = (g + ws - 1) / ws, wtok = nw * nw * ws * ws;
+  const int64_t M = (int64_t)mb * n;
+  const int groups = D / 64;
+  int rc;
+  VDR_TRY(hipMemsetAsync(w.h, 0, (size_t)mb * wtok * D * 2, s), "memset(window padding)");
+  for (int i = 0; i < c.layers; ++i) {
+    const LayerW& L = m->layers[i];
+    const bool glob = (c.global_mask >> i) & 1;
+    const int S = glob ? g : ws;
+    const int64_t T = glob ? M : (int64_t)mb * wtok;
+    const int nb = glob ? mb : mb * nw * nw;
+    char* hbuf = glob ? w.hg : w.h;
+    {
+      LnArgs a{};
+      a.x = w.x;
+      a.in_bf16 = 1;
+      a.y = hbuf;
+      a.out_bf16 = 1;
+      a.gamma = L.n1w;
+      a.beta = L.n1b;
+      a.rows = M;
+      a.D = D;
+      a.eps = c.ln_eps;
+      a.imap = identity_map();
+      a.omap = identity_map();
+      if (!glob) {
+        a.win_ws = ws;
+        a.win_g = g;
+      }
+      Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 4);
+      VDR_TRY(launch_layernorm(a, s), "layernorm(window)");
+    }
+    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS))) return rc;
+    {
+      Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)S * S * S * S * 64.0 * H * nb + 2.0 * T * H * 2 * S * 64,
+               2.0 * (double)T * 4 * D);
+      VDR_TRY(launch_relpos(w.qkv, L.relh, L.relw, w.rel, T, S * S, S, H, s), "relpos");
+      VDR_TRY(launch_attention_relpos(w.qkv, w.rel, w.o, nb, S, H, s), "attention_relpos");
+    }
+    {
+      GemmArgs ga{};
+      ga.A = w.o;
+      ga.W = L.wproj;
+      ga.bias = L.bproj;
+      ga.resid = w.x;
+      ga.C = w.x;
+      ga.M = T;
+      ga.N = D;
+      ga.K = D;
+      ga.lda = D;
+      ga.ldw = D;
+      ga.ldc = D;
+      ga.ldr = D;
+      ga.omap = identity_map();
+      if (!glob) {
+        ga.win_ws = ws;
+        ga.win_g = g;
+      }
+      if (m->ln_fuse) {
+        ga.ln_part = w.part;
+        ga.part_stride = w.Mp;
+      }
+      Scope sc(m, s, VDR_K_GEMM_PROJ, 2.0 * T * D * D, 2.0 * ((double)T * D + (double)D * D + 2.0 * M * D));
+      VDR_TRY(launch_gemm(ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ), s), "proj gemm");
+    }
+    if (m->ln_fuse) {
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
+        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
+      }
+      LnFold cons;
+      cons.stats = w.stats;
+      cons.colsum = L.s1;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU, cons))) return rc;
+    } else {
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.hg, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.hg, L.w1, L.b1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU))) return rc;
+    }
+    if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, nullptr, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
+  }
+  if (tokens_only) {
+    Scope sc(m, s, VDR_K_FINAL_LN, 0.0, (double)M * D * 6);
+    VDR_TRY(launch_gather_rows(w.x, out, out_dtype == VDR_BF16, M, D, identity_map(), s), "gather_rows");
+    return VDR_OK;
+  }
+  // neck: 1x1 conv (no bias) -> LayerNorm2d -> 3x3 conv pad 1 (no bias) -> LayerNorm2d, all on NHWC tokens
+  if ((rc = gemm(m, s, VDR_K_GEMM_PATCH, w.x, m->w_neck0, nullptr, nullptr, nullptr, w.qkv, M, C, D, C, EPI_BIAS))) return rc;
+  if ((rc = layernorm(m, s, VDR_K_FINAL_LN, w.qkv, 1, w.o, 1, m->neck1w, m->neck1b, M, identity_map(), nullptr, 0, C))) return rc;
+  {
+    Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)M * C * 2 * 10);
+    VDR_TRY(launch_im2col3(w.o, w.u, mb, g, C, s), "im2col3");
+  }
+  if ((rc = gemm(m, s, VDR_K_GEMM_PATCH, w.u, m->w_neck2, nullptr, nullptr, nullptr, w.hg, M, C, 9 * C, C, EPI_BIAS))) return rc;
+  return layernorm(m, s, VDR_K_FINAL_LN, w.hg, 1, out, out_dtype == VDR_BF16, m->neck3w, m->neck3b, M, identity_map(), nullptr,
+                   0, C);
+}
+
 // slice (and final-normalise) the token buffer into the caller's output
 int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_mode, int out_dtype, char* out) {
   const vdr_config& c = m->cfg;
@@ -610,6 +757,17 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
     return fail(nullptr, VDR_ERR_UNSUPPORTED, "token models carry no learned pos_embed");
   }
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
+  if (c.window > 0) {
+    const int g = c.patch ? c.img / c.patch : 0;
+    auto side_ok = [](int v) { return v == 4 || v == 7 || v == 10 || v == 14 || v == 64; };
+    if (!c.patch || c.has_cls || !c.has_pos || !c.pre_ln || c.input_ln || c.layerscale || c.act != VDR_ACT_GELU)
+      return fail(nullptr, VDR_ERR_INVALID, "SAM encoder: needs patch > 0, has_cls = 0, has_pos = 1, pre_ln = 1, GELU, no LayerScale");
+    if (c.neck_chans <= 0 || c.neck_chans % 64 || c.neck_chans > 2048)
+      return fail(nullptr, VDR_ERR_UNSUPPORTED, "SAM encoder: neck_chans must be a positive multiple of 64");
+    if (!side_ok(c.window) || c.window == 64 || (c.global_mask && !side_ok(g)))
+      return fail(nullptr, VDR_ERR_UNSUPPORTED, "SAM encoder: window side in {4,7,10,14}, grid side of global blocks in {4,7,10,14,64}");
+    if (c.layers > 31) return fail(nullptr, VDR_ERR_UNSUPPORTED, "SAM encoder: at most 31 blocks");
+  }
   int rc = check_device(nullptr);
   if (rc) return rc;
   int ndev = 0;
@@ -714,6 +872,18 @@ int vdr_set_weight(vdr_handle m, const char* name, const float* host, const int6
       bytes = (size_t)numel * 2;
       break;
     }
+    case W_CONV3_BF16: {
+      // [C_out, C_in, 3, 3] -> [C_out][j * C_in + c], j = ky*3 + kx (tap-major so that im2col3 moves
+      // 8 channels of one tap with a single 16-byte load)
+      const int64_t Cin = s.cols / 9;
+      bf.resize(numel);
+      for (int64_t co = 0; co < s.rows; ++co)
+        for (int64_t ci = 0; ci < Cin; ++ci)
+          for (int64_t j = 0; j < 9; ++j) bf[co * s.cols + j * Cin + ci] = f32_to_bf16(host[(co * Cin + ci) * 9 + j]);
+      src = bf.data();
+      bytes = (size_t)numel * 2;
+      break;
+    }
     case W_W12_BIAS: {
       fv.resize(numel);
       for (int64_t pr = 0; pr < 2 * F; ++pr) {
@@ -749,8 +919,10 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
   if (!c.patch) return fail(m, VDR_ERR_INVALID, "vdr_forward needs an image model (patch > 0)");
   if (in_dtype != VDR_F32 && in_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "in_dtype");
   if (out_dtype != VDR_F32 && out_dtype != VDR_BF16) return fail(m, VDR_ERR_INVALID, "out_dtype");
-  if (out_mode < VDR_OUT_CLS || out_mode > VDR_OUT_TOKENS) return fail(m, VDR_ERR_INVALID, "out_mode");
+  if (out_mode < VDR_OUT_CLS || out_mode > VDR_OUT_ENCODER) return fail(m, VDR_ERR_INVALID, "out_mode");
   if (out_mode == VDR_OUT_CLS && !c.has_cls) return fail(m, VDR_ERR_INVALID, "model has no cls token");
+  if ((out_mode == VDR_OUT_ENCODER) != (c.window > 0 && out_mode != VDR_OUT_PATCH_EMBED && out_mode != VDR_OUT_TOKENS))
+    return fail(m, VDR_ERR_INVALID, "VDR_OUT_ENCODER is the output of a SAM encoder (window > 0); other models use CLS/DENSE/TOKENS");
   int rc = check_device(m);
   if (rc) return rc;
   if (!m->resolved && (rc = resolve(m))) return rc;
@@ -814,6 +986,12 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
         VDR_TRY(launch_gather_rows(w.x, (char*)out + (size_t)b0 * n * D * 4, 0, (int64_t)mb * n, D, identity_map(), s),
                 "gather_rows");
       }
+      continue;
+    }
+    if (c.window > 0) {
+      const bool tok = out_mode == VDR_OUT_TOKENS;
+      const size_t orow_b = tok ? out_row_bytes(m, out_dtype) : (size_t)c.neck_chans * (out_dtype == VDR_BF16 ? 2 : 4);
+      if ((rc = run_sam(m, s, w, mb, out_dtype, (char*)out + (size_t)b0 * n * orow_b, tok))) return rc;
       continue;
     }
     if (c.has_cls) {
@@ -946,6 +1124,16 @@ int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, 
   int rc = check_device(nullptr);
   if (rc) return rc;
   OP_TRY(launch_attention(qkv, out, batch, seq, heads, variant, (hipStream_t)stream), "attention");
+  return VDR_OK;
+}
+
+int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float* rel_pos_w, float* rel, void* out,
+                            int batch, int S, int heads, void* stream) {
+  if (!qkv || !rel_pos_h || !rel_pos_w || !rel || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_relpos(qkv, rel_pos_h, rel_pos_w, rel, (int64_t)batch * S * S, S * S, S, heads, (hipStream_t)stream), "relpos");
+  OP_TRY(launch_attention_relpos(qkv, rel, out, batch, S, heads, (hipStream_t)stream), "attention_relpos");
   return VDR_OK;
 }
 

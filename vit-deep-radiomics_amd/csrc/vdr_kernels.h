@@ -34,6 +34,9 @@ struct GemmArgs {
   //   producer side: per output row and 64-column group, (sum, sum of squares) of the bf16 outputs
   float* ln_part = nullptr;         // [N/64][part_stride][2] fp32 or null
   int64_t part_stride = 0;
+  // SAM window un-partition on the OUTPUT rows: GEMM row m is a token of a ws x ws window (windows
+  // row-major over the zero-padded grid); it lands at token (y, x) of the g x g grid, padding is dropped
+  int win_ws = 0, win_g = 0;
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
@@ -54,11 +57,25 @@ struct LnArgs {
   RowMap omap;
   const float* cls;  // or null
   int cls_period;
+  // SAM window partition on the OUTPUT rows (input rows are tokens of a g x g grid, row-major)
+  int win_ws = 0, win_g = 0;
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 
 hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
                             hipStream_t s);
+
+// SAM / MedSAM decomposed relative position bias (attention_relpos.hip)
+//   rel [tokens][heads][2S] fp32 = (q . Rh[qh - kh + S-1], q . Rw[qw - kw + S-1]); qkv rows are S*S-token
+//   windows (or whole grids) back to back
+hipError_t launch_relpos(const void* qkv, const float* rel_h, const float* rel_w, float* rel, int64_t tokens, int seq,
+                         int S, int heads, hipStream_t s);
+//   softmax(q k^T / 8 + rel_h[kh] + rel_w[kw]) v per (window, head); S in {4, 7, 10, 14} single pass, 64 chunked
+hipError_t launch_attention_relpos(const void* qkv, const float* rel, void* out, int batch, int S, int heads,
+                                   hipStream_t s);
+
+// 3x3 / pad 1 im2col over NHWC tokens of a g x g grid: col[r][j*C + c] = y[(y+ky-1, x+kx-1)][c], j = ky*3 + kx
+hipError_t launch_im2col3(const void* y, void* col, int batch, int g, int C, hipStream_t s);
 
 // images NCHW -> col [batch*n, Kp] bf16 with k = c*p*p + ky*p + kx, zero padded to Kp
 hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libvdr.so")
 
 VDR_F32, VDR_BF16 = 0, 1
 ACT_GELU, ACT_SWIGLU = 0, 1
-OUT_CLS, OUT_DENSE, OUT_PATCH_EMBED, OUT_TOKENS = 0, 1, 2, 3
+OUT_CLS, OUT_DENSE, OUT_PATCH_EMBED, OUT_TOKENS, OUT_ENCODER = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
 K_COUNT = 10
 
@@ -26,7 +26,8 @@ class vdr_config(C.Structure):
                 ("heads", C.c_int32), ("layers", C.c_int32), ("mlp_hidden", C.c_int32), ("act", C.c_int32),
                 ("pre_ln", C.c_int32), ("layerscale", C.c_int32), ("has_cls", C.c_int32), ("has_pos", C.c_int32),
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
-                ("streams", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("streams", C.c_int32), ("window", C.c_int32),
+                ("global_mask", C.c_int32), ("neck_chans", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)
@@ -46,6 +47,7 @@ SYMBOLS = {
     "vdr_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P]),
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "vdr_op_attention_relpos": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vdr_op_patch_embed": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vdr_profile_enable": (_I, [_P, _I]),
     "vdr_profile_mask": (_I, [_P, C.c_uint32]),

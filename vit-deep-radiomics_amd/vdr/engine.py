@@ -30,6 +30,9 @@ class VdrConfig:
     ln_eps: float = 1e-6
     micro_batch: int = 0
     streams: int = 0
+    window: int = 0            # SAM: windowed attention side (14) + decomposed rel-pos
+    global_blocks: tuple = ()  # SAM: blocks with global attention (2, 5, 8, 11)
+    neck_chans: int = 0        # SAM: conv neck output channels (256)
 
     @property
     def n_patches(self):
@@ -47,6 +50,8 @@ class VdrConfig:
         c.pre_ln, c.layerscale, c.has_cls, c.has_pos = int(self.pre_ln), int(self.layerscale), int(self.has_cls), int(self.has_pos)
         c.input_ln, c.ln_eps, c.micro_batch = int(self.input_ln), float(self.ln_eps), int(self.micro_batch)
         c.streams = int(self.streams)
+        c.window, c.neck_chans = int(self.window), int(self.neck_chans)
+        c.global_mask = sum(1 << int(i) for i in self.global_blocks)
         return c
 
 
@@ -122,7 +127,9 @@ class Engine:
         images = images.to(self.device).contiguous()
         B = images.shape[0]
         n, N, D = cfg.n_patches, cfg.n_tokens, cfg.dim
-        shape = {L.OUT_CLS: (B, D), L.OUT_DENSE: (B, n, D), L.OUT_PATCH_EMBED: (B, n, D), L.OUT_TOKENS: (B, N, D)}[out_mode]
+        g = cfg.img // cfg.patch
+        shape = {L.OUT_CLS: (B, D), L.OUT_DENSE: (B, n, D), L.OUT_PATCH_EMBED: (B, n, D), L.OUT_TOKENS: (B, N, D),
+                 L.OUT_ENCODER: (B, g, g, cfg.neck_chans)}[out_mode]
         out = torch.empty(shape, dtype=out_dtype, device=self.device)
         ws = self._workspace(B)
         L.check(self.lib.vdr_forward(self.h, images.data_ptr(), _DT[images.dtype], B, out.data_ptr(), out_mode,

@@ -24,7 +24,22 @@ ARCHS = {
     "dinov2_giant14_224": VdrConfig(224, 14, 3, 1536, 24, 40, 4096, act="swiglu", layerscale=True),
     # reference default for model_name='dinov2' (load_dinov2('small'), run at 896x896)
     "dinov2": VdrConfig(896, 14, 3, 384, 6, 12, 1536, layerscale=True),
+    # reference default backbone: sam_model_registry['vit_b'] image encoder (MedSAM checkpoint), 1024x1024
+    "medsam": VdrConfig(1024, 16, 3, 768, 12, 12, 3072, has_cls=False, window=14, global_blocks=(2, 5, 8, 11),
+                        neck_chans=256),
 }
+
+
+def from_sam_state_dict(sd):
+    """segment_anything checkpoint keys (image_encoder.* of sam_model_registry['vit_b'](path),
+    tfds_dense_descriptor.py:104) -> the canonical names vdr_set_weight understands."""
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith("image_encoder."):
+            continue
+        k = k[len("image_encoder."):].replace(".mlp.lin1.", ".mlp.fc1.").replace(".mlp.lin2.", ".mlp.fc2.")
+        out[k] = v
+    return out
 
 
 class VitDescriptorModel:
@@ -54,9 +69,11 @@ class VitDescriptorModel:
 
     def image_encoder(self, x: torch.Tensor) -> torch.Tensor:
         """Channel-first dense map [B,D,h,w], the layout tfds_dense_descriptor.py:123-126 squeezes and
-        transposes to (h,w,D)."""
+        transposes to (h,w,D).  SAM / MedSAM models return the conv-neck output [B,256,64,64]."""
         B = x.shape[0]
         g = self.cfg.img // self.cfg.patch
+        if self.cfg.window > 0:
+            return self.engine.forward(x, L.OUT_ENCODER, torch.float32).permute(0, 3, 1, 2)
         dense = self.engine.forward(x, L.OUT_DENSE, torch.float32)
         return dense.reshape(B, g, g, self.cfg.dim).permute(0, 3, 1, 2)
 
@@ -68,15 +85,13 @@ class VitDescriptorModel:
         return self.engine.forward(x, L.OUT_DENSE, out_dtype)
 
     def __call__(self, x):
-        return self.forward_features(x)
+        return self.image_encoder(x) if self.cfg.window > 0 else self.forward_features(x)
 
 
 def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
     torch.load(weights_only=True).  weights: the same dict passed directly."""
-    if model_name == "medsam":
-        raise NotImplementedError("the SAM ViT-B@1024 windowed-attention encoder is SURVEY.md §8 row f-1 (next)")
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
     cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams})
@@ -84,6 +99,8 @@ def load_model(model_name: str, model_path=None, weights=None, device=None, micr
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
         weights = torch.load(model_path, map_location="cpu", weights_only=True)
+    if model_name == "medsam" and any(k.startswith("image_encoder.") for k in weights):
+        weights = from_sam_state_dict(weights)
     model = VitDescriptorModel(cfg, weights, model_name, device)
     model.model_name = model_name
     return model
