@@ -193,7 +193,8 @@ int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, 
  * tfds_dense_descriptor.py:123): per (window, head) softmax(q k^T dh^-0.5 + q.Rh[qh-kh] + q.Rw[qw-kw]) v.
  *   qkv   [batch*S*S, 3*H*64] bf16, `batch` windows (or whole grids) of S x S tokens, row-major (h, w)
  *   rel_pos_h / rel_pos_w  fp32 [2S-1, 64] (the block's parameters)
- *   rel   device scratch, fp32 [batch*S*S*H*2S]
+ *   rel   device scratch, fp32 [batch*S*S*H*Np + Np*32], Np = 2*roundup(2S-1, 32): the products of q with
+ *         every relative-offset row of both tables (one MFMA GEMM) and, behind them, the packed bf16 tables
  *   out   [batch*S*S, H*64] bf16.   S in {4, 7, 10, 14} (one pass) or 64 (online softmax). */
 int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float* rel_pos_w, float* rel, void* out,
                             int batch, int S, int heads, void* stream);

@@ -7,8 +7,8 @@
 // for S x S token grids: the 14 x 14 windows (196 tokens, zero-padded border windows included) and the
 // four global blocks over the whole 64 x 64 grid (4096 tokens).
 //
-// relpos_kernel   : rel[token][head][0..S) = q . Rh[qh - kh + S-1],  rel[...][S..2S) = q . Rw[qw - kw + S-1]
-//                   (fp32; 2S dot products of length 64 per token and head)
+// relpos_pack_kernel: both rel-pos tables as one [Npad][64] bf16 GEMM operand; T = q . table^T (fp32, all
+//                   2(2S-1) relative offsets per token and head) is a GEMM in gemm.hip
 // attn_relpos_kernel<NT, S, MULTI>: the fused attention of attention.hip (K in swizzled LDS, V^T in LDS,
 //                   S^T = K.Q^T so a softmax row is lane-local, P fed back as an MFMA operand) with the bias
 //                   added to the logits from registers: the key of accumulator element (t, e, half) is a
@@ -20,48 +20,37 @@
 namespace vdr {
 
 // ---------------------------------------------------------------------------------------------------
-// rel-pos pre-pass: one wave per (token, head); lane j < 2S owns output j
+// rel-pos table packing: [Npad][64] bf16, rel_pos_h rows at 0, rel_pos_w rows at Npad/2, zero elsewhere.
+// The products T[(token, head)][j] = q . table[j] are then ONE MFMA GEMM over (token, head) rows
+// (launch_gemm with the two-stride A row map), and the attention kernel picks
+//   rel_h[kh] = T[qh - kh + S-1],   rel_w[kw] = T[Npad/2 + qw - kw + S-1]
+// with per-lane base offsets and compile-time kh / kw.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void relpos_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
-                                                     const float* __restrict__ rel_w, float* __restrict__ rel,
-                                                     int64_t tokens, int seq, int S, int heads) {
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // token * heads + head
-  if (item >= tokens * heads) return;
-  const int64_t tok = item / heads;
-  const int hd = (int)(item - tok * heads);
-  const int pos = (int)(tok % seq);  // position inside the window / grid
-  const int qh = pos / S, qw = pos - qh * S;
-  const bf16_t* q = qkv + tok * (int64_t)(3 * heads * 64) + hd * 64;
-  const float qv = (float)q[lane];  // lane c holds q[c]
-  float* dst = rel + item * (int64_t)(2 * S);
-  for (int j0 = 0; j0 < 2 * S; j0 += 64) {
-    const int j = j0 + lane;
-    const bool act = j < 2 * S;
-    const int jj = act ? j : 0;
-    const bool is_h = jj < S;
-    const int kk = is_h ? jj : jj - S;
-    const float* row = (is_h ? rel_h + (int64_t)(qh - kk + S - 1) * 64 : rel_w + (int64_t)(qw - kk + S - 1) * 64);
-    float acc = 0.0f;
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) acc = fmaf(__shfl(qv, c, 64), row[c], acc);
-    if (act) dst[j] = acc;
-  }
+__global__ __launch_bounds__(256) void relpos_pack_kernel(const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w,
+                                                          bf16_t* __restrict__ table, int S, int npad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= npad * 64) return;
+  const int row = i >> 6, c = i & 63;
+  const int half = npad >> 1, n = 2 * S - 1;
+  float v = 0.0f;
+  if (row < n) v = rel_h[row * 64 + c];
+  else if (row >= half && row < half + n) v = rel_w[(row - half) * 64 + c];
+  table[i] = (bf16_t)v;
 }
 
-hipError_t launch_relpos(const void* qkv, const float* rel_h, const float* rel_w, float* rel, int64_t tokens, int seq,
-                         int S, int heads, hipStream_t s) {
-  if (tokens <= 0 || S <= 0 || S * S != seq) return hipErrorInvalidValue;
-  const int64_t items = tokens * heads;
-  hipLaunchKernelGGL(relpos_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, (const bf16_t*)qkv, rel_h, rel_w,
-                     rel, tokens, seq, S, heads);
+hipError_t launch_relpos_pack(const float* rel_h, const float* rel_w, void* table, int S, hipStream_t s) {
+  if (S <= 0) return hipErrorInvalidValue;
+  const int npad = relpos_npad(S);
+  hipLaunchKernelGGL(relpos_pack_kernel, dim3((unsigned)((npad * 64 + 255) / 256)), dim3(256), 0, s, rel_h, rel_w,
+                     (bf16_t*)table, S, npad);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
 struct AttnRK {
   const bf16_t* qkv;
-  const float* rel;  // [batch*seq][heads][2S]
+  const float* T;  // [batch*seq][heads][relpos_npad(S)]
   bf16_t* out;
   int seq, heads;
   int64_t ld_qkv, ld_out;
@@ -103,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   bf16x8 qf[4];
   constexpr int NRW = S;                 // rel_w values kept in registers
   constexpr int NRH = MULTI ? 2 : S;     // rel_h values: the whole column, or the chunk's two grid rows
+  constexpr int NPAD = 2 * ((2 * S - 1 + 31) / 32 * 32);  // relpos_npad(S)
   float relw[NRW], relh[NRH];
   const float* relrow = nullptr;
 
@@ -112,12 +102,15 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     const bf16_t* src = qb + (int64_t)q * p.ld_qkv + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
-    relrow = p.rel + (((int64_t)b * p.seq + q) * p.heads + hd) * (2 * S);
+    const int qh = q / S, qw = q - qh * S;
+    const float* trow = p.T + (((int64_t)b * p.seq + q) * p.heads + hd) * NPAD;
+    relrow = trow + qh + (S - 1);  // rel_h[kh] = relrow[-kh]
+    const float* wrow = trow + NPAD / 2 + qw + (S - 1);
 #pragma unroll
-    for (int j = 0; j < NRW; ++j) relw[j] = relrow[S + j];
+    for (int j = 0; j < NRW; ++j) relw[j] = wrow[-j];
     if (!MULTI) {
 #pragma unroll
-      for (int j = 0; j < NRH; ++j) relh[j] = relrow[j];
+      for (int j = 0; j < NRH; ++j) relh[j] = relrow[-j];
     }
 #pragma unroll
     for (int nd = 0; nd < 2; ++nd)
@@ -174,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   auto process = [&](int kc0, bool rescale) {
     if (MULTI) {
       // this chunk covers grid rows kc0/64 and kc0/64 + 1
-      relh[0] = relrow[kc0 >> 6];
-      relh[1] = relrow[min((kc0 >> 6) + 1, S - 1)];
+      relh[0] = relrow[-(kc0 >> 6)];
+      relh[1] = relrow[-min((kc0 >> 6) + 1, S - 1)];
     }
     f32x16 s[NT];
 #pragma unroll
@@ -312,12 +305,12 @@ static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_attention_relpos(const void* qkv, const float* rel, void* out, int batch, int S, int heads,
+hipError_t launch_attention_relpos(const void* qkv, const float* T, void* out, int batch, int S, int heads,
                                    hipStream_t s) {
   if (batch <= 0 || S <= 0 || heads <= 0) return hipErrorInvalidValue;
   AttnRK k;
   k.qkv = (const bf16_t*)qkv;
-  k.rel = rel;
+  k.T = T;
   k.out = (bf16_t*)out;
   k.seq = S * S;
   k.heads = heads;

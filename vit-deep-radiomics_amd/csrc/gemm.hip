@@ -41,6 +41,9 @@ struct GemmK {
   const float* colsum;
   float* ln_part;
   int64_t part_stride;
+  int a_rpg;
+  int64_t a_gs, a_is;
+  int out_f32;
   int win_ws, win_g;  // SAM window un-partition of the output rows (0 = off)
   int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
@@ -204,6 +207,18 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
         v[4 + e] += p1[e];
       }
     }
+  }
+  if (p.out_f32) {
+    float* dst = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = v[e];
+      hi[e] = v[4 + e];
+    }
+    *reinterpret_cast<f32x4*>(dst) = lo;
+    *reinterpret_cast<f32x4*>(dst + 4) = hi;
+    return orow;
   }
   bf16x8 o;
 #pragma unroll
@@ -668,7 +683,8 @@ VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, cha
     const int c = spc ^ ((r >> 2) & 3);
     int64_t gr = m0 + r;
     gr = gr < p.M ? gr : p.M - 1;
-    a_src[q] = p.A + gr * p.lda + c * 8;
+    const int64_t aoff = p.a_rpg > 0 ? (gr / p.a_rpg) * p.a_gs + (gr % p.a_rpg) * p.a_is : gr * p.lda;
+    a_src[q] = p.A + aoff + c * 8;
   }
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -982,6 +998,10 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   }
   k.win_ws = a.win_ws;
   k.win_g = a.win_g;
+  k.a_rpg = a.a_rpg;
+  k.a_gs = a.a_gs;
+  k.a_is = a.a_is;
+  k.out_f32 = a.out_f32;
   k.ln_stats = a.ln_stats;
   k.colsum = a.colsum;
   k.ln_part = a.ln_part;
@@ -1033,7 +1053,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
   g_gemm_ablation = variant / 100;
   variant %= 100;
-  if ((a.ln_stats || a.ln_part || a.win_ws) && variant < 12) return hipErrorInvalidValue;  // needs epilogue_lds (ring2)
+  if ((a.ln_stats || a.ln_part || a.win_ws || a.a_rpg || a.out_f32) && variant < 12) return hipErrorInvalidValue;
+  if (a.out_f32 && epilogue != EPI_BIAS) return hipErrorInvalidValue;  // needs epilogue_lds (ring2)
   if (a.ln_part && (a.N & 63)) return hipErrorInvalidValue;
   switch (variant) {
     case 0:

@@ -48,6 +48,7 @@ struct LayerW {
   // LayerNorm folded into the consuming GEMM (pre-LN image models): W' = W.diag(gamma) in bf16,
   // colsum[n] = sum_k W'[n][k], tbias[n] = sum_k beta[k] W[n][k] + b[n]
   const float *relh = nullptr, *relw = nullptr;  // SAM decomposed relative position tables
+  void* reltab = nullptr;  // both tables packed as one [relpos_npad(S)][64] bf16 GEMM operand
   void *wqkv_f = nullptr, *w1_f = nullptr;
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
@@ -301,6 +302,17 @@ int resolve(vdr_model* m) {
       if (rc) return rc;
     }
   }
+  if (c.window > 0) {
+    VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+    const int g = c.img / c.patch;
+    for (int i = 0; i < c.layers; ++i) {
+      LayerW& L = m->layers[i];
+      const int S = (c.global_mask >> i) & 1 ? g : c.window;
+      if (!L.reltab) VDR_TRY(hipMalloc(&L.reltab, (size_t)relpos_npad(S) * 64 * 2 + 256), "hipMalloc(rel-pos table)");
+      VDR_TRY(launch_relpos_pack(L.relh, L.relw, L.reltab, S, nullptr), "relpos_pack");
+    }
+    VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
   for (auto& sl : m->slots) std::vector<float>().swap(sl.host);  // host copies are no longer needed
   m->resolved = true;
   return VDR_OK;
@@ -324,7 +336,7 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
     const size_t g = c.img / c.patch, ws = c.window, nw = (g + ws - 1) / ws;
     const size_t wtok = nw * nw * ws * ws;
     if (wtok > (size_t)ntok) rows = (size_t)mb * wtok;
-    const size_t rw = (size_t)mb * wtok * c.heads * 2 * ws, rg = (size_t)mb * ntok * c.heads * 2 * g;
+    const size_t rw = (size_t)mb * wtok * c.heads * relpos_npad((int)ws), rg = (size_t)mb * ntok * c.heads * relpos_npad((int)g);
     rel_floats = rw > rg ? rw : rg;
   }
   const size_t Mp = (size_t)round_up((int)rows, 256) + 256;
@@ -434,9 +446,12 @@ int env_int(const char* name, int dflt) {
 }
 
 // tile configuration per GEMM class; VDR_GEMM_VARIANT overrides all of them (tuning aid)
-int gemm_variant_for(int cls) {
+int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   static const int forced = env_int("VDR_GEMM_VARIANT", -1);
   if (forced >= 0) return forced;
+  // small problems (a single 1024^2 SAM slice is M = 4096): fewer 128x256 tiles than CUs -> 128x128 tiles
+  // (measured, MedSAM batch 1: fc2 0.72 -> 0.57 ms, proj 0.35 -> 0.31 ms per forward)
+  if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) return 16;
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
   switch (cls) {
@@ -477,7 +492,7 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
-  VDR_TRY(launch_gemm(g, epi, gemm_variant_for(cls), s), "gemm");
+  VDR_TRY(launch_gemm(g, epi, gemm_variant_for(cls, M, N), s), "gemm");
   return VDR_OK;
 }
 
@@ -584,6 +599,28 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
 // SAM / MedSAM ImageEncoderViT blocks + neck over x [mb * g*g rows] (tokens NHWC, pos_embed already added).
 // Window blocks: LN1 writes the window-partitioned, zero-padded order (padding rows of w.h stay zero),
 // qkv / rel-pos / attention run on windows, the proj epilogue un-partitions while adding the residual.
+// T[(token, head)][j] = q . table[j] for every relative offset j of both axes: one GEMM whose A rows are the
+// per-head q slices of the packed qkv activation (M = tokens * heads, N = relpos_npad(S), K = 64), fp32 out.
+hipError_t relpos_products(const void* qkv, const void* table, float* T, int64_t tokens, int S, int heads, hipStream_t s) {
+  GemmArgs ga{};
+  ga.A = qkv;
+  ga.W = table;
+  ga.C = T;
+  ga.M = tokens * heads;
+  ga.N = relpos_npad(S);
+  ga.K = 64;
+  ga.lda = 64;
+  ga.ldw = 64;
+  ga.ldc = ga.N;
+  ga.ldr = ga.N;
+  ga.omap = identity_map();
+  ga.a_rpg = heads;
+  ga.a_gs = (int64_t)3 * heads * 64;
+  ga.a_is = 64;
+  ga.out_f32 = 1;
+  return launch_gemm(ga, EPI_BIAS, ga.N <= 128 ? 20 : 19, s);
+}
+
 int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, char* out, bool tokens_only) {
   const vdr_config& c = m->cfg;
   const int D = c.dim, F = c.mlp_hidden, H = c.heads, C = c.neck_chans;
@@ -621,9 +658,9 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
     }
     if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS))) return rc;
     {
-      Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)S * S * S * S * 64.0 * H * nb + 2.0 * T * H * 2 * S * 64,
+      Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)S * S * S * S * 64.0 * H * nb + 2.0 * T * H * relpos_npad(S) * 64,
                2.0 * (double)T * 4 * D);
-      VDR_TRY(launch_relpos(w.qkv, L.relh, L.relw, w.rel, T, S * S, S, H, s), "relpos");
+      VDR_TRY(relpos_products(w.qkv, L.reltab, w.rel, T, S, H, s), "relpos");
       VDR_TRY(launch_attention_relpos(w.qkv, w.rel, w.o, nb, S, H, s), "attention_relpos");
     }
     {
@@ -650,7 +687,7 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
         ga.part_stride = w.Mp;
       }
       Scope sc(m, s, VDR_K_GEMM_PROJ, 2.0 * T * D * D, 2.0 * ((double)T * D + (double)D * D + 2.0 * M * D));
-      VDR_TRY(launch_gemm(ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ), s), "proj gemm");
+      VDR_TRY(launch_gemm(ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ, ga.M, ga.N), s), "proj gemm");
     }
     if (m->ln_fuse) {
       {
@@ -794,6 +831,7 @@ void vdr_destroy(vdr_handle h) {
     if (s.dev) hipFree(s.dev);
   for (auto& L : h->layers) {
     if (L.wqkv_f) hipFree(L.wqkv_f);
+    if (L.reltab) hipFree(L.reltab);
     if (L.w1_f) hipFree(L.w1_f);
     if (L.sqkv) hipFree(L.sqkv);
     if (L.tqkv) hipFree(L.tqkv);
@@ -978,7 +1016,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       }
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
-      VDR_TRY(launch_gemm(g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH), s), "patch gemm");
+      VDR_TRY(launch_gemm(g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, g.M, g.N), s), "patch gemm");
     }
     if (pe_only) {
       if (out_dtype != VDR_BF16) {
@@ -1130,9 +1168,14 @@ int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, 
 int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float* rel_pos_w, float* rel, void* out,
                             int batch, int S, int heads, void* stream) {
   if (!qkv || !rel_pos_h || !rel_pos_w || !rel || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (batch <= 0 || S <= 0 || heads <= 0) return fail(nullptr, VDR_ERR_INVALID, "bad shape");
   int rc = check_device(nullptr);
   if (rc) return rc;
-  OP_TRY(launch_relpos(qkv, rel_pos_h, rel_pos_w, rel, (int64_t)batch * S * S, S * S, S, heads, (hipStream_t)stream), "relpos");
+  const int64_t tokens = (int64_t)batch * S * S;
+  const int npad = relpos_npad(S);
+  void* table = rel + tokens * heads * npad;  // packed bf16 tables behind the products
+  OP_TRY(launch_relpos_pack(rel_pos_h, rel_pos_w, table, S, (hipStream_t)stream), "relpos_pack");
+  OP_TRY(relpos_products(qkv, table, rel, tokens, S, heads, (hipStream_t)stream), "relpos");
   OP_TRY(launch_attention_relpos(qkv, rel, out, batch, S, heads, (hipStream_t)stream), "attention_relpos");
   return VDR_OK;
 }

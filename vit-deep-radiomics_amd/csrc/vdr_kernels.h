@@ -37,6 +37,11 @@ struct GemmArgs {
   // SAM window un-partition on the OUTPUT rows: GEMM row m is a token of a ws x ws window (windows
   // row-major over the zero-padded grid); it lands at token (y, x) of the g x g grid, padding is dropped
   int win_ws = 0, win_g = 0;
+  // A rows gathered with two strides: row m starts at element (m / a_rpg) * a_gs + (m % a_rpg) * a_is
+  // (a_rpg = 0: plain m * lda).  Used to read the per-head q slices of a packed qkv activation as rows.
+  int a_rpg = 0;
+  int64_t a_gs = 0, a_is = 0;
+  int out_f32 = 0;  // C is fp32 (EPI_BIAS only)
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
@@ -68,10 +73,13 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
 // SAM / MedSAM decomposed relative position bias (attention_relpos.hip)
 //   rel [tokens][heads][2S] fp32 = (q . Rh[qh - kh + S-1], q . Rw[qw - kw + S-1]); qkv rows are S*S-token
 //   windows (or whole grids) back to back
-hipError_t launch_relpos(const void* qkv, const float* rel_h, const float* rel_w, float* rel, int64_t tokens, int seq,
-                         int S, int heads, hipStream_t s);
-//   softmax(q k^T / 8 + rel_h[kh] + rel_w[kw]) v per (window, head); S in {4, 7, 10, 14} single pass, 64 chunked
-hipError_t launch_attention_relpos(const void* qkv, const float* rel, void* out, int batch, int S, int heads,
+//   table [Npad][64] bf16: rows [0, 2S-1) = rel_pos_h, rows [Npad/2, Npad/2 + 2S-1) = rel_pos_w, rest zero;
+//   Npad = relpos_npad(S).  T = q . table^T is one GEMM over (token, head) rows (launch_gemm with a_rpg).
+static inline int relpos_npad(int S) { return 2 * ((2 * S - 1 + 31) / 32 * 32); }
+hipError_t launch_relpos_pack(const float* rel_h, const float* rel_w, void* table, int S, hipStream_t s);
+//   softmax(q k^T / 8 + T[qh - kh + S-1] + T[Npad/2 + qw - kw + S-1]) v per (window, head);
+//   T fp32 [batch*S*S*heads][Npad]; S in {4, 7, 10, 14} single pass, 64 chunked
+hipError_t launch_attention_relpos(const void* qkv, const float* T, void* out, int batch, int S, int heads,
                                    hipStream_t s);
 
 // 3x3 / pad 1 im2col over NHWC tokens of a g x g grid: col[r][j*C + c] = y[(y+ky-1, x+kx-1)][c], j = ky*3 + kx

@@ -89,7 +89,8 @@ def attention_relpos(qkv: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torc
     assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     assert qkv.shape == (batch * S * S, 3 * heads * 64)
     assert rel_pos_h.shape == (2 * S - 1, 64) and rel_pos_w.shape == (2 * S - 1, 64)
-    rel = torch.empty(batch * S * S * heads * 2 * S, dtype=torch.float32, device=qkv.device)
+    npad = 2 * ((2 * S - 1 + 31) // 32 * 32)
+    rel = torch.empty(batch * S * S * heads * npad + npad * 32, dtype=torch.float32, device=qkv.device)
     out = torch.empty((batch * S * S, heads * 64), dtype=torch.bfloat16, device=qkv.device)
     L.check(lib.vdr_op_attention_relpos(qkv.data_ptr(), rel_pos_h.float().contiguous().data_ptr(),
                                         rel_pos_w.float().contiguous().data_ptr(), rel.data_ptr(), out.data_ptr(), batch, S,
