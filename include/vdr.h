@@ -182,6 +182,28 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
                   const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
                   void* stream);
 
+/* ---- MX-fp8 operators (BASELINE config 5: "DINOv2 ViT-g/14 fp8 weights (CDNA4 fp8 MFMA)") ----------
+ * An MX tensor X[rows, K] is an OCP e4m3 payload q[rows, K] (one byte per element) plus e8m0 scales, one per
+ * 32 consecutive K elements, in the device layout  s[K/32][rows_pad]  (rows_pad = rows rounded up to 256; inside
+ * each 64-row group rows are stored as (r, r+32) pairs).  vdr_mx_scale_bytes gives the size of that array.
+ * The reference has no fp8 path (fp32 eager everywhere); these replace the same nn.Linear / nn.LayerNorm
+ * call sites as vdr_op_linear / vdr_op_layernorm (models_archs.py:130-136, ViT blocks). */
+size_t vdr_mx_scale_bytes(int64_t rows, int K);
+/* bf16 x [rows, K] -> MX (q, scales).  K % 32 == 0. */
+int vdr_op_mx_quantize(const void* x, int64_t rows, int K, void* q, void* scales, void* stream);
+/* MX (q, scales) -> fp32 y [rows, K]  (test / inspection helper: value = e4m3(q) * 2^(scale-127)) */
+int vdr_op_mx_dequantize(const void* q, const void* scales, int64_t rows, int K, float* y, void* stream);
+/* F.layer_norm over bf16 rows with MX output (the operand of the following fp8 linear).  D % 32 == 0. */
+int vdr_op_layernorm_mx(const void* x, const float* gamma, const float* beta, float eps, int64_t rows, int D,
+                        void* q, void* scales, void* stream);
+/* F.linear with MX operands on the block-scaled fp8 MFMA, fp32 accumulate, same epilogues as vdr_op_linear.
+ *   xq/xs: MX x [M, K];  wq/ws: MX W [N, K];  y bf16 [M, N] ([M, N/2] for EPI_SWIGLU), or — when yscales is
+ *   non-NULL (EPI_BIAS_GELU / EPI_SWIGLU only) — an MX tensor (y = payload, yscales) ready for the next
+ *   fp8 linear.  K % 64 == 0, N % 64 == 0.  variant: 0 = 128x256 tile, 1 = 256x256, 2 = 128x128. */
+int vdr_op_linear_mx(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
+                     const void* resid, const float* gamma, void* y, void* yscales, int64_t M, int N, int K,
+                     int epilogue, int variant, void* stream);
+
 /* F.scaled_dot_product_attention over a packed qkv activation — the core of
  * nn.MultiheadAttention (models_archs.py:130) / Attention.forward of the ViTs.
  *   qkv [batch*seq, 3*H*64] bf16, row = token, columns [q | k | v] each [H, 64]

@@ -224,6 +224,21 @@ def gen_sam_hf(tag, img, patch, dim, heads, layers, ffn, window, global_idx, out
     assert err < 1e-4, err
 
 
+def gen_e4m3fn_table():
+    """(iv) fp8 tables: the 256-entry e4m3fn decode table and a quantise/dequantise vector, both from
+    torch.float8_e4m3fn casts on the CPU (the reference has no fp8 path; this pins oracle/mx_oracle.py)."""
+    from oracle import mx_oracle as mx
+
+    tab = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(7, 96, generator=g) * torch.logspace(-6, 5, 7)[:, None]
+    x[2, 32:64] = 0
+    q, e = mx.mx_quantize(x)
+    d = mx.mx_dequantize(q, e)
+    np.savez(os.path.join(HERE, "e4m3fn_table.npz"), decode=tab, x=x.numpy(), payload=q.view(torch.uint8).numpy(),
+             exponent=e.numpy(), dequant=d.numpy())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     # (i) tiny, (ii) the reference's configured dims (conf/parameters_models.yaml:4,14-16),
@@ -237,3 +252,4 @@ if __name__ == "__main__":
     # SAM geometry in miniature: 10x10 grid, window 4 (padded to 12 -> 9 windows), one global block
     gen_sam_hf("tiny", 160, 16, 64, 1, 3, 128, 4, (1,), 32, 2, wseed=41, xseed=9)
     gen_sam_hf("w7", 224, 16, 128, 2, 2, 256, 7, (1,), 64, 1, wseed=42, xseed=10)
+    gen_e4m3fn_table()

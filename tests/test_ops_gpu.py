@@ -290,3 +290,117 @@ def test_attention_relpos_global_grid_64(ops):
     ref = _relpos_attn_ref(qkv, rel_h, rel_w, B, S, H)
     out = ops.attention_relpos(qkv.cuda(), rel_h.cuda(), rel_w.cuda(), B, S, H)
     _assert_close(out, ref, 2 * BF16_EPS, 6e-3, "relpos attention global 64x64")
+
+
+# ---- MX-fp8 (BASELINE config 5) -------------------------------------------------------------------
+def _mx_ref(x):
+    from oracle import mx_oracle as mx
+
+    return mx.mx_round(x.float().cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(1, 32), (70, 96), (300, 768), (513, 4096)])
+def test_mx_quantize_bitexact_vs_oracle(rows, K):
+    """quantise on the GPU, dequantise on the GPU: bitwise the oracle's quantise/dequantise (covers the
+    scale layout, zero blocks, a wide dynamic range)."""
+    from vdr import ops
+
+    g = torch.Generator().manual_seed(rows * 7 + K)
+    x = torch.randn(rows, K, generator=g) * torch.logspace(-5, 4, rows)[:, None]
+    if rows > 2:
+        x[1, :32] = 0.0
+    xb = x.to(torch.bfloat16)
+    t = ops.mx_quantize(xb.cuda())
+    got = t.dequantize().cpu()
+    want = _mx_ref(xb)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (300, 192, 256), (1000, 512, 1536), (257, 1536, 4096)])
+def test_linear_mx_integer_exact(M, N, K, variant):
+    """small-integer operands with per-block power-of-two magnitudes: every product and partial sum is exact in
+    fp32 and the result is exact in bf16 -> the MX GEMM must be BIT-exact (operand layout, scale routing,
+    opsel, edge tiles)."""
+    from vdr import ops
+
+    g = torch.Generator().manual_seed(M + N + K + variant)
+    # values in {-2..2} * 2^s with a per-(row, block) shift s in {0, 1, 2}: scales differ between blocks
+    xs = torch.randint(0, 3, (M, K // 32, 1), generator=g)
+    ws = torch.randint(0, 3, (N, K // 32, 1), generator=g)
+    x = (torch.randint(-2, 3, (M, K // 32, 32), generator=g) * (2 ** xs)).reshape(M, K).float()
+    w = (torch.randint(-2, 3, (N, K // 32, 32), generator=g) * (2 ** ws)).reshape(N, K).float()
+    # keep |sum| small enough for bf16 to hold it exactly: thin out the operands for large K
+    keep = torch.rand(M, K, generator=g) < min(1.0, 48.0 / K)
+    x = x * keep
+    ref = x.double() @ w.double().t()
+    assert float(ref.abs().max()) < 2 ** 15
+    xq = ops.mx_quantize(x.to(torch.bfloat16).cuda())
+    wq = ops.mx_quantize(w.to(torch.bfloat16).cuda())
+    assert torch.equal(xq.dequantize().cpu(), x) and torch.equal(wq.dequantize().cpu(), w)
+    y = ops.linear_mx(xq, wq, variant=variant).float().cpu()
+    want = ref.float().to(torch.bfloat16).float()
+    assert torch.equal(y, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid", "swiglu"])
+def test_linear_mx_epilogues_vs_dequantised_reference(epi):
+    """random operands: the MX GEMM equals F.linear on the DEQUANTISED operands (fp32) up to one bf16 rounding
+    of the output, for every fused epilogue."""
+    from vdr import ops, _lib as L
+
+    M, N, K = 777, 512, 768
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    xq, wq = ops.mx_quantize(x.cuda()), ops.mx_quantize(w.cuda())
+    acc = (xq.dequantize().double() @ wq.dequantize().double().t()).cpu() + b.double()
+    if epi == "bias":
+        y = ops.linear_mx(xq, wq, bias=b.cuda())
+        want = acc
+    elif epi == "gelu":
+        y = ops.linear_mx(xq, wq, bias=b.cuda(), epilogue=L.EPI_BIAS_GELU)
+        want = torch.nn.functional.gelu(acc)
+    elif epi == "resid":
+        r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+        gam = 1.0 + 0.1 * torch.randn(N, generator=g)
+        y = ops.linear_mx(xq, wq, bias=b.cuda(), resid=r.cuda(), gamma=gam.cuda(), epilogue=L.EPI_BIAS_RESID)
+        want = r.double() + gam.double() * acc
+    else:
+        wp, bp = ops.pack_w12(w, b)
+        wq2 = ops.mx_quantize(wp.cuda())
+        acc2 = (xq.dequantize().double() @ wq2.dequantize().double().t()).cpu() + bp.double()
+        # un-interleave the gate pairs of the packed layout: blocks of 64 = [32 x1 | 32 x2]
+        a = acc2.reshape(M, N // 64, 2, 32)
+        want = (torch.nn.functional.silu(a[:, :, 0]) * a[:, :, 1]).reshape(M, N // 2)
+        y = ops.linear_mx(xq, wq2, bias=bp.cuda(), epilogue=L.EPI_SWIGLU)
+    y = y.float().cpu()
+    want = want.float()
+    err = (y - want).abs()
+    tol = 2.0 ** -8 * want.abs() + 1e-3
+    assert bool((err <= tol).all()), float((err / (want.abs() + 1e-3)).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,D", [(5, 64), (197, 768), (300, 1536)])
+def test_layernorm_mx_vs_oracle(rows, D):
+    """LayerNorm with MX output: dequantised result within half an e4m3 ulp (2^-4 relative to the block
+    maximum) of the fp32 LayerNorm, and bitwise the oracle quantiser applied to the kernel's own fp32 result
+    on all but rounding-boundary elements."""
+    from vdr import ops
+
+    g = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=g) * 3 + 0.5).to(torch.bfloat16)
+    gam = 1.0 + 0.1 * torch.randn(D, generator=g)
+    bet = 0.1 * torch.randn(D, generator=g)
+    t = ops.layernorm_mx(x.cuda(), gam.cuda(), bet.cuda(), 1e-6)
+    got = t.dequantize().cpu()
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gam, bet, 1e-6)
+    blockmax = ref.reshape(rows, D // 32, 32).abs().amax(-1, keepdim=True).expand(-1, -1, 32).reshape(rows, D)
+    assert bool(((got - ref).abs() <= blockmax * (2.0 ** -4) * 1.02 + 1e-6).all())
+    want = _mx_ref(ref)
+    assert float((got != want).float().mean()) < 2e-3

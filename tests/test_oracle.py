@@ -106,3 +106,26 @@ def test_sam_flops_formula():
     from oracle import sam_oracle as so
     # SAM ViT-B @ 1024^2 is ~0.94 TFLOP per slice
     assert abs(so.flops_per_image(so.SAM_VIT_B) / 1e12 - 0.94) < 0.08
+
+
+def test_mx_fp8_quantiser_matches_golden_table(golden_dir):
+    """oracle/mx_oracle.py vs the committed torch.float8_e4m3fn fixture (SURVEY §8c golden (iv))."""
+    from oracle import mx_oracle as mx
+
+    g = np.load(os.path.join(golden_dir, "e4m3fn_table.npz"))
+    mine = mx.e4m3_decode_table()
+    assert np.array_equal(np.isnan(mine), np.isnan(g["decode"]))
+    assert np.array_equal(np.nan_to_num(mine), np.nan_to_num(g["decode"]))
+    x = torch.from_numpy(g["x"])
+    q, e = mx.mx_quantize(x)
+    assert np.array_equal(q.view(torch.uint8).numpy(), g["payload"])
+    assert np.array_equal(e.numpy(), g["exponent"])
+    assert np.array_equal(mx.mx_dequantize(q, e).numpy(), g["dequant"])
+    # properties: never saturates, block maximum lands in (224, 448], zero blocks stay zero, half-ulp error bound
+    qa = q.to(torch.float32).abs().reshape(x.shape[0], -1, 32).amax(-1)
+    assert float(qa.max()) <= 448.0
+    nz = x.reshape(x.shape[0], -1, 32).abs().amax(-1) > 0
+    assert bool((qa[nz] > 224.0).all()) and bool((qa[~nz] == 0).all())
+    d = mx.mx_dequantize(q, e)
+    blockmax = x.reshape(x.shape[0], -1, 32).abs().amax(-1, keepdim=True).expand(-1, -1, 32).reshape(x.shape)
+    assert bool(((d - x).abs() <= blockmax * 2.0 ** -4 * 1.0001 + 1e-30).all())

@@ -14,344 +14,10 @@
 // per register group: the epilogue then reads bias/residual and writes bf16 8 bytes at a time.
 #include <cstdlib>
 
-#include "vdr_dev.h"
-#include "vdr_kernels.h"
+#include "gemm_epi.h"
 
 namespace vdr {
 
-struct GemmK {
-  const bf16_t* A;
-  const bf16_t* W;
-  const float* bias;
-  const bf16_t* resid;
-  const float* gamma;
-  const float* pos;
-  bf16_t* C;
-  int64_t M;
-  int N, K;
-  int64_t lda, ldw, ldc, ldr;
-  int rpg;
-  int64_t gstride;
-  int off;
-  int tiles_n;
-  int nwg;
-  int nwg_big;      // ring2: workgroups [0, nwg_big) use the full tile height, the rest half of it
-  int64_t m_split;  // ring2: first row covered by half-height tiles
-  const float* ln_stats;
-  const float* colsum;
-  float* ln_part;
-  int64_t part_stride;
-  int a_rpg;
-  int64_t a_gs, a_is;
-  int out_f32;
-  int win_ws, win_g;  // SAM window un-partition of the output rows (0 = off)
-  int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
-  int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
-  int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
-};
-
-// Epilogue math for 4 consecutive output columns n..n+3 of output row m (v2 = SwiGLU gate partner).
-template <int EPI>
-VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, int n) {
-  if (m >= p.M || n >= p.N) return;
-  int64_t orow = m;
-  int prow = 0;
-  if (EPI == EPI_PATCH) {
-    const int64_t g = m / p.rpg;
-    const int i = (int)(m - g * p.rpg);
-    orow = g * p.gstride + p.off + i;
-    prow = p.off + i;
-  }
-  if (p.bias) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += b[e];
-  }
-  if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-  }
-  if (EPI == EPI_SWIGLU) {
-    // u is the gate partner (x2); its bias sits 32 packed rows further
-    if (p.bias) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] += b2[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = silu(v[e]) * u[e];
-  }
-  if (EPI == EPI_BIAS_RESID) {
-    if (p.gamma) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gm[e];
-    }
-    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + orow * p.ldr + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-  }
-  if (EPI == EPI_PATCH) {
-    if (p.pos) {
-      const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += ps[e];
-    }
-  }
-  bf16x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-  int oc = n;
-  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);  // packed column 64*blk + t (t < 32) -> feature 32*blk + t
-  *reinterpret_cast<bf16x4*>(p.C + orow * p.ldc + oc) = o;
-}
-
-// Same math for 8 consecutive columns n..n+7: residual read and output store are 16 bytes per lane
-// (a store wave-instruction costs ~80-100 cycles of the CU's store path whatever its width, so the
-// epilogue is written with the widest ones).
-typedef __attribute__((ext_vector_type(8))) float f32x8;
-template <int EPI>
-VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2,
-                        float mu = 0.0f, float rs = 1.0f) {
-  sum1 = 0.0f;
-  sum2 = 0.0f;
-  if (m >= p.M || n >= p.N) return -1;
-  int64_t orow = m;
-  int prow = 0;
-  if (EPI == EPI_PATCH) {
-    const int64_t g = m / p.rpg;
-    const int i = (int)(m - g * p.rpg);
-    orow = g * p.gstride + p.off + i;
-    prow = p.off + i;
-  }
-  if (p.win_ws > 0) {
-    // window un-partition (segment_anything window_unpartition): row m of the windowed order -> token (y, x)
-    const int ws = p.win_ws, g = p.win_g, nw = (g + ws - 1) / ws;
-    const int64_t widx = m / (ws * ws);
-    const int wtok = (int)(m - widx * (ws * ws));
-    const int wx = (int)(widx % nw);
-    const int64_t t2 = widx / nw;
-    const int wy = (int)(t2 % nw);
-    const int64_t b = t2 / nw;
-    const int y = wy * ws + wtok / ws, x = wx * ws + wtok % ws;
-    if (y >= g || x >= g) return -1;  // zero padding of the border windows: dropped
-    orow = (b * g + y) * g + x;
-  }
-  if (p.ln_stats) {
-    // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
-    // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.colsum + n);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = rs * (v[e] - mu * c0[e]);
-      v[4 + e] = rs * (v[4 + e] - mu * c1[e]);
-    }
-    if (EPI == EPI_SWIGLU) {
-      const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.colsum + n + 32);
-      const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 36);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        u[e] = rs * (u[e] - mu * d0[e]);
-        u[4 + e] = rs * (u[4 + e] - mu * d1[e]);
-      }
-    }
-  }
-  if (p.bias) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] += b0[e];
-      v[4 + e] += b1[e];
-    }
-  }
-  if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-  }
-  if (EPI == EPI_SWIGLU) {
-    if (p.bias) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 36);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        u[e] += b0[e];
-        u[4 + e] += b1[e];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
-  }
-  if (EPI == EPI_BIAS_RESID) {
-    if (p.gamma) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] *= g0[e];
-        v[4 + e] *= g1[e];
-      }
-    }
-    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.resid + orow * p.ldr + n);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-  }
-  if (EPI == EPI_PATCH) {
-    if (p.pos) {
-      const f32x4 p0 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-      const f32x4 p1 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += p0[e];
-        v[4 + e] += p1[e];
-      }
-    }
-  }
-  if (p.out_f32) {
-    float* dst = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
-    f32x4 lo, hi;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      lo[e] = v[e];
-      hi[e] = v[4 + e];
-    }
-    *reinterpret_cast<f32x4*>(dst) = lo;
-    *reinterpret_cast<f32x4*>(dst + 4) = hi;
-    return orow;
-  }
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    o[e] = (bf16_t)v[e];
-    const float r = (float)o[e];  // statistics of what the consumer will actually read
-    sum1 += r;
-    sum2 = fmaf(r, r, sum2);
-  }
-  int oc = n;
-  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
-  *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
-  return orow;
-}
-
-// Direct-from-accumulator epilogue: this lane owns row m and columns n_base + 8g + 4h + e of a
-// 32 (n) x 32 (m) accumulator tile.
-template <int EPI>
-VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc2, int64_t m, int n_base,
-                            int h) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v[4], u[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = acc[4 * g + e];
-      u[e] = acc2[4 * g + e];
-    }
-    epi_quad<EPI>(p, v, u, m, n_base + 8 * g + 4 * h);
-  }
-}
-
-// LDS-staged epilogue: the accumulators of a 32 (m) x 64 (n) block go through a wave-private fp32
-// staging image (row stride 272 B: conflict-free ds_write_b128 / ds_read_b128) and come back with
-// 16 lanes per output row, so every global access of the epilogue (bias, residual, store) touches
-// whole 128-B lines instead of 32 rows x 16 B per instruction.
-template <int EPI, int TM, int TN>
-VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int64_t m_base, int n_base, int lane) {
-  constexpr int RS = 272;
-  static_assert(TN % 2 == 0, "column tiles are staged in pairs");
-  const int h = lane >> 5, l31 = lane & 31;
-  // LayerNorm fold: (mean, rstd) of the 4*TM rows this lane owns in the read-back phase, fetched up front
-  float st_mu[TM][4], st_rs[TM][4];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      st_mu[i][rr] = 0.0f;
-      st_rs[i][rr] = 1.0f;
-      if (p.ln_stats) {
-        int64_t m = m_base + i * 32 + rr * 8 + (lane >> 3);
-        m = m < p.M ? m : p.M - 1;
-        const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
-        st_mu[i][rr] = t.x;
-        st_rs[i][rr] = t.y;
-      }
-    }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int jp = 0; jp < TN / 2; ++jp) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 t;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = acc[2 * jp + jj][i][4 * g + e];
-          *reinterpret_cast<f32x4*>(stg + l31 * RS + (jj * 32 + 8 * g + 4 * h) * 4) = t;
-        }
-      if (EPI != EPI_SWIGLU) {
-        // 8 lanes per row (8 columns each), 8 rows per instruction: whole 128-B lines, 16-B accesses
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int row = rr * 8 + (lane >> 3), c8 = lane & 7;
-          const f32x4 t0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32);
-          const f32x4 t1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32 + 16);
-          float v[8], u[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = u[e] = t0[e];
-            v[4 + e] = u[4 + e] = t1[e];
-          }
-          float s1, s2;
-          const int64_t orow = epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2,
-                                            st_mu[i][rr], st_rs[i][rr]);
-          if (p.ln_part) {
-            // the 8 lanes of a row hold its 64 columns of this block: (sum, sumsq) -> one slot per
-            // (row, 64-column group), written exactly once: no atomics, no zeroing, deterministic
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-              s1 += __shfl_xor(s1, o, 64);
-              s2 += __shfl_xor(s2, o, 64);
-            }
-            const int grp = (n_base + jp * 64) >> 6;
-            if (c8 == 0 && orow >= 0 && n_base + jp * 64 < p.N) {
-              float* dst = p.ln_part + ((int64_t)grp * p.part_stride + orow) * 2;
-              dst[0] = s1;
-              dst[1] = s2;
-            }
-          }
-        }
-      } else {
-        // gate pairs: columns 0..31 of the block are x1, 32..63 the matching x2 -> 32 outputs per row
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int row = rr * 16 + (lane >> 2), c8 = lane & 3;
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32 + 16);
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(stg + row * RS + 128 + c8 * 32);
-          const f32x4 g1 = *reinterpret_cast<const f32x4*>(stg + row * RS + 128 + c8 * 32 + 16);
-          float v[8], u[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = a0[e];
-            v[4 + e] = a1[e];
-            u[e] = g0[e];
-            u[4 + e] = g1[e];
-          }
-          float s1, s2, mu = 0.0f, rs = 1.0f;
-          if (p.ln_stats) {
-            int64_t m = m_base + i * 32 + row;
-            m = m < p.M ? m : p.M - 1;
-            const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
-            mu = t.x;
-            rs = t.y;
-          }
-          epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2, mu, rs);
-        }
-      }
-    }
-  }
-}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmK p) {
@@ -504,11 +170,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(GemmK p) {
 // workgroup streaming from L2 at all times, which is what the per-CU L2->LDS path needs to reach its
 // rate (the earlier variants issue a burst, drain it, and sit at ~half of it).
 // -------------------------------------------------------------------------------------------------
-template <int N>
-VDR_DEV void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int WAVES_M, int WAVES_N, int TM, int TN, int NST, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 2 : 2)) void gemm_ring_kernel(GemmK p) {
   constexpr int NW = WAVES_M * WAVES_N;

@@ -1157,6 +1157,62 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
   return VDR_OK;
 }
 
+size_t vdr_mx_scale_bytes(int64_t rows, int K) { return rows > 0 && K > 0 ? mx_scale_bytes(rows, K) : 0; }
+
+int vdr_op_mx_quantize(const void* x, int64_t rows, int K, void* q, void* scales, void* stream) {
+  if (!x || !q || !scales) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_mx_quant(x, rows, K, K, q, scales, (hipStream_t)stream), "mx_quantize");
+  return VDR_OK;
+}
+
+int vdr_op_mx_dequantize(const void* q, const void* scales, int64_t rows, int K, float* y, void* stream) {
+  if (!q || !scales || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_mx_dequant(q, scales, rows, K, y, (hipStream_t)stream), "mx_dequantize");
+  return VDR_OK;
+}
+
+int vdr_op_layernorm_mx(const void* x, const float* gamma, const float* beta, float eps, int64_t rows, int D, void* q,
+                        void* scales, void* stream) {
+  if (!x || !gamma || !beta || !q || !scales) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_ln_mx(x, gamma, beta, eps, rows, D, q, scales, (hipStream_t)stream), "layernorm_mx");
+  return VDR_OK;
+}
+
+int vdr_op_linear_mx(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, const void* resid,
+                     const float* gamma, void* y, void* yscales, int64_t M, int N, int K, int epilogue, int variant,
+                     void* stream) {
+  if (!xq || !xs || !wq || !ws || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (epilogue == VDR_EPI_BIAS_RESID && !resid) return fail(nullptr, VDR_ERR_INVALID, "EPI_BIAS_RESID needs resid");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  GemmArgs g{};
+  g.A = xq;
+  g.a_scale = xs;
+  g.W = wq;
+  g.w_scale = ws;
+  g.bias = bias;
+  g.resid = resid;
+  g.gamma = gamma;
+  g.C = y;
+  g.c_scale = yscales;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldw = K;
+  g.ldc = epilogue == VDR_EPI_SWIGLU ? N / 2 : N;
+  g.ldr = g.ldc;
+  g.omap = identity_map();
+  OP_TRY(launch_gemm_mx(g, epilogue, variant, (hipStream_t)stream), "gemm_mx");
+  return VDR_OK;
+}
+
 int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant, void* stream) {
   if (!qkv || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
   int rc = check_device(nullptr);

@@ -42,6 +42,10 @@ struct GemmArgs {
   int a_rpg = 0;
   int64_t a_gs = 0, a_is = 0;
   int out_f32 = 0;  // C is fp32 (EPI_BIAS only)
+  // MX-fp8 GEMM (launch_gemm_mx): A and W are e4m3 payloads, *_scale their e8m0 scale arrays (mx.hip layout)
+  const void* a_scale = nullptr;
+  const void* w_scale = nullptr;
+  void* c_scale = nullptr;  // non-null: C is written as MX-fp8 (payload [M][ldc] bytes + scales), not bf16
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
@@ -75,6 +79,18 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
 //   windows (or whole grids) back to back
 //   table [Npad][64] bf16: rows [0, 2S-1) = rel_pos_h, rows [Npad/2, Npad/2 + 2S-1) = rel_pos_w, rest zero;
 //   Npad = relpos_npad(S).  T = q . table^T is one GEMM over (token, head) rows (launch_gemm with a_rpg).
+// ---- MX-fp8 (mx.hip, gemm_mx.hip) ---------------------------------------------------------------------
+static inline int64_t mx_rows_pad(int64_t rows) { return (rows + 255) / 256 * 256; }
+static inline size_t mx_scale_bytes(int64_t rows, int K) { return (size_t)mx_rows_pad(rows) * (size_t)(K / 32); }
+//   bf16 [rows][K] (row stride ldx elements) -> e4m3 payload [rows][K] + e8m0 scales
+hipError_t launch_mx_quant(const void* x, int64_t rows, int K, int64_t ldx, void* q, void* scales, hipStream_t s);
+hipError_t launch_mx_dequant(const void* q, const void* scales, int64_t rows, int K, float* y, hipStream_t s);
+//   LayerNorm over bf16 rows, MX out
+hipError_t launch_ln_mx(const void* x, const float* gamma, const float* beta, float eps, int64_t rows, int D, void* q,
+                        void* scales, hipStream_t s);
+//   C = epi(A . W^T) with MX operands; variant 0: 128x256 tile / 8 waves, 1: 256x256 / 16 waves, 2: 128x128 / 4 waves
+hipError_t launch_gemm_mx(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
+
 static inline int relpos_npad(int S) { return 2 * ((2 * S - 1 + 31) / 32 * 32); }
 hipError_t launch_relpos_pack(const float* rel_h, const float* rel_w, void* table, int S, hipStream_t s);
 //   softmax(q k^T / 8 + T[qh - kh + S-1] + T[Npad/2 + qw - kw + S-1]) v per (window, head);

@@ -46,6 +46,11 @@ SYMBOLS = {
     "vdr_forward_tokens": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, C.c_size_t, _P]),
     "vdr_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P]),
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "vdr_mx_scale_bytes": (C.c_size_t, [_L, _I]),
+    "vdr_op_mx_quantize": (_I, [_P, _L, _I, _P, _P, _P]),
+    "vdr_op_mx_dequantize": (_I, [_P, _P, _L, _I, _P, _P]),
+    "vdr_op_layernorm_mx": (_I, [_P, _P, _P, _F, _L, _I, _P, _P, _P]),
+    "vdr_op_linear_mx": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vdr_op_attention_relpos": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vdr_op_patch_embed": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -41,6 +41,68 @@ def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant
     return out
 
 
+class MxTensor:
+    """e4m3 payload [rows, K] (uint8) + e8m0 block scales in the device layout of csrc/mx.hip."""
+
+    def __init__(self, q: torch.Tensor, scales: torch.Tensor):
+        self.q, self.scales = q, scales
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    @staticmethod
+    def empty(rows: int, K: int, device):
+        lib = L.load()
+        return MxTensor(torch.empty((rows, K), dtype=torch.uint8, device=device),
+                        torch.zeros(int(lib.vdr_mx_scale_bytes(rows, K)), dtype=torch.uint8, device=device))
+
+    def dequantize(self) -> torch.Tensor:
+        lib = L.load()
+        rows, K = self.q.shape
+        y = torch.empty((rows, K), dtype=torch.float32, device=self.q.device)
+        L.check(lib.vdr_op_mx_dequantize(self.q.data_ptr(), self.scales.data_ptr(), rows, K, y.data_ptr(), _s(self.q)))
+        return y
+
+
+def mx_quantize(x: torch.Tensor) -> MxTensor:
+    """bf16 [rows, K] -> MX-fp8 (block 32 along K)."""
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] % 32 == 0
+    rows, K = x.shape
+    t = MxTensor.empty(rows, K, x.device)
+    L.check(lib.vdr_op_mx_quantize(x.data_ptr(), rows, K, t.q.data_ptr(), t.scales.data_ptr(), _s(x)))
+    return t
+
+
+def layernorm_mx(x: torch.Tensor, gamma, beta, eps: float) -> MxTensor:
+    lib = L.load()
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
+    rows, D = x.shape
+    t = MxTensor.empty(rows, D, x.device)
+    L.check(lib.vdr_op_layernorm_mx(x.data_ptr(), gamma.float().contiguous().data_ptr(), beta.float().contiguous().data_ptr(),
+                                    float(eps), rows, D, t.q.data_ptr(), t.scales.data_ptr(), _s(x)))
+    return t
+
+
+def linear_mx(x: MxTensor, W: MxTensor, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, mx_out=False):
+    """MX x [M,K] . MX W [N,K]^T on the block-scaled fp8 MFMA; returns bf16 [M,N] or (mx_out) an MxTensor."""
+    lib = L.load()
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    No = N // 2 if epilogue == L.EPI_SWIGLU else N
+    if mx_out:
+        out = MxTensor.empty(M, No, x.q.device)
+        yp, ysp = out.q.data_ptr(), out.scales.data_ptr()
+    else:
+        out = torch.empty((M, No), dtype=torch.bfloat16, device=x.q.device)
+        yp, ysp = out.data_ptr(), None
+    L.check(lib.vdr_op_linear_mx(x.q.data_ptr(), x.scales.data_ptr(), W.q.data_ptr(), W.scales.data_ptr(), _p(bias),
+                                 _p(resid), _p(gamma), yp, ysp, M, N, K, epilogue, variant, _s(x.q)))
+    return out
+
+
 def pack_w12(w12: torch.Tensor, b12: torch.Tensor):
     """Interleave SwiGLU x1/x2 rows in blocks of 32 (the layout vdr_set_weight builds for mlp.w12)."""
     F2 = w12.shape[0]
