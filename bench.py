@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense MX-fp8, same table
 PEAK_HBM_GBS = 8000.0
 
 GEMM_CLASSES = ("gemm_patch", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2", "attention")
@@ -94,6 +95,8 @@ def main():
     ap.add_argument("--model", type=str, default="vit_base16_224")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
+    ap.add_argument("--fp8", action="store_true",
+                    help="qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline dtype)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
@@ -126,7 +129,7 @@ def main():
     else:
         ocfg = vo.CONFIGS[a.model]
         weights = vo.make_weights(ocfg, seed=1)
-    model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams)
+    model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
@@ -211,21 +214,23 @@ def main():
                 traffic = round((pm[key]["read_mb_corrected"] + pm[key]["write_mb"]) * 1e6)
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.txt)",
+        # fp8 run: the qkv / fc1 / fc2 GEMMs are priced against the dense fp8 peak, everything else against bf16
+        peak = PEAK_FP8_TFLOPS if a.fp8 and dom in ("gemm_qkv", "gemm_fc1", "gemm_fc2") else PEAK_BF16_TFLOPS
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.txt)",
                 "avg_launch_ms": round(dv["ms"] / dv["launches"], 4),
                 "flops_per_launch": dv["flops"] / dv["launches"],
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof_all.values()), 3)}
         out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
-               else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
-                     else f"images/sec, {a.model} CLS-feature extraction"),
+               and not a.fp8 else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
+                     else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} CLS-feature extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16", "data": "synthetic",
+               "dtype": "fp8 (MX e4m3 qkv/fc1/fc2, bf16 elsewhere)" if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
                                        f"[{total},64,64,256] fp32" if sam else
-                                       f"{a.model} {ocfg.img}^2 bf16, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32")
+                                       f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32")
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "micro_batch": a.micro_batch, "streams": a.streams},

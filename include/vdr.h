@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 1
+#define VDR_ABI_VERSION 2
 
 typedef enum {
   VDR_OK = 0,
@@ -98,6 +98,9 @@ typedef struct {
                       /* bias in every block; needs has_cls = 0, has_pos = 1, pre_ln = 1               */
   int32_t global_mask;/* bit i set: block i attends over the whole grid (SAM ViT-B: 2,5,8,11 = 0x924)  */
   int32_t neck_chans; /* output channels of the conv neck (256); 1x1 conv, LN2d, 3x3 conv, LN2d        */
+  /* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"): */
+  int32_t fp8;        /* 1: qkv / fc1 (w12) / fc2 (w3) weights are kept as MX-fp8 (OCP e4m3 + e8m0 scale per 32 K      */
+                      /* elements) and run on v_mfma_scale_f32_32x32x64_f8f6f4 with MX-fp8 activations; pre_ln only    */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

@@ -36,12 +36,12 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=False):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
                        has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
-                       micro_batch=micro_batch)
+                       micro_batch=micro_batch, fp8=fp8)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -160,6 +160,66 @@ def test_dinov2_giant14_geometry_swiglu_layerscale():
     e = _engine(cfg, w)
     _gate(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emu["cls"], gate_l2(2), gate_l2(2), "dinov2_giant14 cls")
     _gate(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emu["dense"], gate_l2(2), gate_l2(2), "dinov2_giant14 dense")
+
+
+def _gate_fp8(got, ref, ref_mx, layers, what):
+    """fp8 gates: cosine >= 0.99 per row against the fp32 oracle (the reference has no fp8 path, so
+    this is parity with its fp32 arithmetic) and relative L2 <= 3e-2 + 3e-2 sqrt(L): an e4m3 element carries
+    ~2.5 % rms rounding error, a K-long dot product of two such operands ~3.5 %, diluted by the residual
+    stream (measured 6.0e-2 at L = 3).  The oracle that emulates the same MX-fp8 quantisation points is printed
+    and gated at the same level, not tighter: the quantiser itself is bit-exact (tests/test_ops_gpu.py), but any
+    bf16-level difference upstream moves elements across e4m3 rounding boundaries (6 % each), so two correct
+    runs decorrelate to roughly the quantisation noise itself."""
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), what
+    r32, rmx, c = _rel_l2(got, ref), _rel_l2(got, ref_mx), _min_cos(got, ref)
+    print(f"{what}: relL2 vs fp32 {r32:.3e}  vs MX-emulating oracle {rmx:.3e}  min cos {c:.6f}")
+    assert c >= 0.99, f"{what}: min cosine {c}"
+    gate = 3e-2 + 3e-2 * math.sqrt(layers)
+    assert r32 <= gate, f"{what}: rel L2 vs fp32 oracle {r32}"
+    assert rmx <= gate, f"{what}: rel L2 vs MX-emulating oracle {rmx}"
+
+
+@pytest.mark.parametrize("name", ["p16_d128", "p14_d192", "dinov2_swiglu_ls"])
+def test_fp8_small_vit_all_outputs(name):
+    """BASELINE config 5 path (MX-fp8 qkv / fc1 / fc2 on the block-scaled MFMA) on the small geometries."""
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=3, scale=0.05)
+    x = vo.make_images(cfg, 5, seed=4)
+    ref = vo.forward_images(cfg, w, x)
+    emx = vo.forward_images(cfg, w, x, emulate_bf16="mx")
+    e = _engine(cfg, w, fp8=True)
+    xd = x.cuda()
+    _gate_fp8(e.forward(xd, vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{name} fp8 cls")
+    _gate_fp8(e.forward(xd, vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{name} fp8 dense")
+    # the fp8 path is still batch-independent and deterministic
+    a = e.forward(xd, vdr.OUT_CLS)
+    b = e.forward(xd[[3, 1, 4, 0, 2]], vdr.OUT_CLS)
+    assert torch.equal(a[[3, 1, 4, 0, 2]], b)
+
+
+def test_fp8_dinov2_giant14_config5_geometry():
+    """BASELINE config 5: DINOv2 ViT-g/14 (D=1536, H=24, SwiGLU 4096, LayerScale, 257 tokens) with fp8 weights,
+    depth cut to 2 blocks for the oracle's sake; plus ViT-B/16 dims (GELU) at 3 blocks."""
+    import vdr
+    full = vo.CONFIGS["dinov2_giant14_224"]
+    for cfg, tag in [(vo.VitCfg(full.img, full.patch, 3, full.dim, full.heads, 2, full.mlp_hidden, act="swiglu", layerscale=True), "vitg"),
+                     (vo.VitCfg(224, 16, 3, 768, 12, 3, 3072), "vitb")]:
+        w = vo.make_weights(cfg, seed=6)
+        x = vo.make_images(cfg, 3, seed=7)
+        ref = vo.forward_images(cfg, w, x)
+        emx = vo.forward_images(cfg, w, x, emulate_bf16="mx")
+        e = _engine(cfg, w, fp8=True)
+        _gate_fp8(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{tag} fp8 cls")
+        _gate_fp8(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{tag} fp8 dense")
+
+
+def test_fp8_is_refused_where_it_is_not_implemented():
+    import vdr
+    with pytest.raises(RuntimeError):
+        vdr.Engine(vdr.VdrConfig(img=0, patch=0, dim=64, heads=1, layers=1, mlp_hidden=128, pre_ln=False, has_pos=False,
+                                 input_ln=True, fp8=True))
 
 
 def test_layernorm_folding_matches_the_explicit_layernorm_path(monkeypatch):

@@ -404,3 +404,43 @@ def test_layernorm_mx_vs_oracle(rows, D):
     assert bool(((got - ref).abs() <= blockmax * (2.0 ** -4) * 1.02 + 1e-6).all())
     want = _mx_ref(ref)
     assert float((got != want).float().mean()) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("epi", ["gelu", "swiglu"])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_linear_mx_output_requantised(epi, variant):
+    """fc1 epilogue writing MX-fp8 directly (the fc2 operand): dequantised output = oracle quantiser applied to
+    the exact epilogue result, up to elements whose fp32 value sits on a rounding boundary."""
+    from vdr import ops, _lib as L
+
+    M, N, K = 333, 512, 768
+    g = torch.Generator().manual_seed(5 + variant)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    xq = ops.mx_quantize(x.cuda())
+    if epi == "gelu":
+        wq = ops.mx_quantize(w.cuda())
+        acc = (xq.dequantize().double() @ wq.dequantize().double().t()).cpu() + b.double()
+        want = torch.nn.functional.gelu(acc).float()
+        t = ops.linear_mx(xq, wq, bias=b.cuda(), epilogue=L.EPI_BIAS_GELU, variant=variant, mx_out=True)
+    else:
+        wp, bp = ops.pack_w12(w, b)
+        wq = ops.mx_quantize(wp.cuda())
+        acc = (xq.dequantize().double() @ wq.dequantize().double().t()).cpu() + bp.double()
+        a = acc.reshape(M, N // 64, 2, 32)
+        want = (torch.nn.functional.silu(a[:, :, 0]) * a[:, :, 1]).reshape(M, N // 2).float()
+        t = ops.linear_mx(xq, wq, bias=bp.cuda(), epilogue=L.EPI_SWIGLU, variant=variant, mx_out=True)
+    got = t.dequantize().cpu()
+    assert got.shape == want.shape
+    ref = _mx_ref(want)
+    blockmax = want.reshape(M, -1, 32).abs().amax(-1, keepdim=True).expand(-1, -1, 32).reshape(want.shape)
+    assert bool(((got - want).abs() <= blockmax * (2.0 ** -4) * 1.02 + 1e-6).all())
+    assert float((got != ref).float().mean()) < 5e-3
+    # and it feeds the next GEMM: same result as quantising the bf16 output with the plain quantiser, within noise
+    w2 = (torch.randn(256, want.shape[1], generator=g) * 0.05).to(torch.bfloat16)
+    w2q = ops.mx_quantize(w2.cuda())
+    y = ops.linear_mx(t, w2q).float().cpu()
+    yref = (got.double() @ w2q.dequantize().double().cpu().t()).float()
+    assert bool(((y - yref).abs() <= 2.0 ** -8 * yref.abs() + 1e-3).all())

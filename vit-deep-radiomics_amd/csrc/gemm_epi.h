@@ -104,15 +104,21 @@ VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, i
 // (a store wave-instruction costs ~80-100 cycles of the CU's store path whatever its width, so the
 // epilogue is written with the widest ones).
 typedef __attribute__((ext_vector_type(8))) float f32x8;
+// EPI_*_MX (gemm_mx.hip only): the same epilogue math, output re-quantised to MX-fp8
+constexpr int epi_base(int e) { return e == EPI_BIAS_GELU_MX ? EPI_BIAS_GELU : e == EPI_SWIGLU_MX ? EPI_SWIGLU : e; }
+constexpr bool epi_mx_out(int e) { return e == EPI_BIAS_GELU_MX || e == EPI_SWIGLU_MX; }
 template <int EPI>
 VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2,
                         float mu = 0.0f, float rs = 1.0f) {
+  constexpr int E = epi_base(EPI);
+  constexpr bool MXO = epi_mx_out(EPI);
+  (void)MXO;
   sum1 = 0.0f;
   sum2 = 0.0f;
   if (m >= p.M || n >= p.N) return -1;
   int64_t orow = m;
   int prow = 0;
-  if (EPI == EPI_PATCH) {
+  if (E == EPI_PATCH) {
     const int64_t g = m / p.rpg;
     const int i = (int)(m - g * p.rpg);
     orow = g * p.gstride + p.off + i;
@@ -141,7 +147,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
       v[e] = rs * (v[e] - mu * c0[e]);
       v[4 + e] = rs * (v[4 + e] - mu * c1[e]);
     }
-    if (EPI == EPI_SWIGLU) {
+    if (E == EPI_SWIGLU) {
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(p.colsum + n + 32);
       const f32x4 d1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 36);
 #pragma unroll
@@ -160,11 +166,11 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
       v[4 + e] += b1[e];
     }
   }
-  if (EPI == EPI_BIAS_GELU) {
+  if (E == EPI_BIAS_GELU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
   }
-  if (EPI == EPI_SWIGLU) {
+  if (E == EPI_SWIGLU) {
     if (p.bias) {
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 36);
@@ -177,7 +183,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
   }
-  if (EPI == EPI_BIAS_RESID) {
+  if (E == EPI_BIAS_RESID) {
     if (p.gamma) {
       const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);
       const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + n + 4);
@@ -191,7 +197,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
   }
-  if (EPI == EPI_PATCH) {
+  if (E == EPI_PATCH) {
     if (p.pos) {
       const f32x4 p0 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
       const f32x4 p1 = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n + 4);
@@ -214,6 +220,35 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     *reinterpret_cast<f32x4*>(dst + 4) = hi;
     return orow;
   }
+  if constexpr (MXO) {
+    // MX-fp8 output (the operand of the next fp8 linear): the 4 lanes that hold 32 consecutive output columns of
+    // this row agree on one e8m0 scale (validity is uniform inside such a quad: N % 64 == 0), each stores 8 bytes
+    int oc8 = n;
+    if (E == EPI_SWIGLU) oc8 = (n >> 6) * 32 + (n & 31);
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    const float t = amax * (1.0f / 448.0f);
+    const uint32_t tb = __float_as_uint(t);
+    int ex = (int)((tb >> 23) & 255) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+    ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+    const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, w1, true);
+    u32x2 o8;
+    o8[0] = (uint32_t)w0;
+    o8[1] = (uint32_t)w1;
+    *reinterpret_cast<u32x2*>(reinterpret_cast<uint8_t*>(p.C) + orow * p.ldc + oc8) = o8;
+    if ((oc8 & 31) == 0)
+      p.sC[(int64_t)(oc8 >> 5) * p.sc_rows + (orow & ~(int64_t)63) + 2 * (orow & 31) + ((orow >> 5) & 1)] =
+          (uint8_t)(ex + 127);
+    return orow;
+  }
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -223,7 +258,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     sum2 = fmaf(r, r, sum2);
   }
   int oc = n;
-  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
+  if (E == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
   *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
   return orow;
 }
@@ -251,6 +286,9 @@ VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc
 // whole 128-B lines instead of 32 rows x 16 B per instruction.
 template <int EPI, int TM, int TN>
 VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int64_t m_base, int n_base, int lane) {
+  constexpr int E = epi_base(EPI);
+  constexpr bool MXO = epi_mx_out(EPI);
+  (void)MXO;
   constexpr int RS = 272;
   static_assert(TN % 2 == 0, "column tiles are staged in pairs");
   const int h = lane >> 5, l31 = lane & 31;
@@ -283,7 +321,7 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
           for (int e = 0; e < 4; ++e) t[e] = acc[2 * jp + jj][i][4 * g + e];
           *reinterpret_cast<f32x4*>(stg + l31 * RS + (jj * 32 + 8 * g + 4 * h) * 4) = t;
         }
-      if (EPI != EPI_SWIGLU) {
+      if (E != EPI_SWIGLU) {
         // 8 lanes per row (8 columns each), 8 rows per instruction: whole 128-B lines, 16-B accesses
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {

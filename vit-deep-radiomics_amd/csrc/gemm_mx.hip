@@ -263,6 +263,8 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     VDR_LAUNCH_MX(EPI_BIAS_GELU)
     VDR_LAUNCH_MX(EPI_BIAS_RESID)
     VDR_LAUNCH_MX(EPI_SWIGLU)
+    VDR_LAUNCH_MX(EPI_BIAS_GELU_MX)
+    VDR_LAUNCH_MX(EPI_SWIGLU_MX)
     default:
       return hipErrorInvalidValue;
   }
@@ -273,7 +275,11 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 hipError_t launch_gemm_mx(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 63) || a.M <= 0 || !a.a_scale || !a.w_scale) return hipErrorInvalidValue;
   if (a.ln_stats || a.win_ws || a.a_rpg || a.out_f32) return hipErrorInvalidValue;
-  if (a.c_scale && epilogue != EPI_BIAS_GELU && epilogue != EPI_SWIGLU) return hipErrorInvalidValue;
+  if (a.c_scale) {  // MX output
+    if (epilogue == EPI_BIAS_GELU) epilogue = EPI_BIAS_GELU_MX;
+    else if (epilogue == EPI_SWIGLU) epilogue = EPI_SWIGLU_MX;
+    else return hipErrorInvalidValue;
+  }
   switch (variant) {
     case 0:
       return launch_mx_cfg<2, 4, 3>(a, epilogue, s);  // 128x256, 8 waves, 3 x 26 KB, 2 workgroups per CU

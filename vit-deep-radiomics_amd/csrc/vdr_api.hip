@@ -50,6 +50,8 @@ struct LayerW {
   const float *relh = nullptr, *relw = nullptr;  // SAM decomposed relative position tables
   void* reltab = nullptr;  // both tables packed as one [relpos_npad(S)][64] bf16 GEMM operand
   void *wqkv_f = nullptr, *w1_f = nullptr;
+  // fp8 path: MX-fp8 copies (payload, scales) of the qkv / fc1 (w12) / fc2 (w3) weights
+  void *qkv_q = nullptr, *qkv_s = nullptr, *w1_q = nullptr, *w1_s = nullptr, *w2_q = nullptr, *w2_s = nullptr;
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
 
@@ -196,7 +198,7 @@ bool ln_fusion_wanted(const vdr_model* m) {
   const vdr_config& c = m->cfg;
   const char* e = getenv("VDR_LN_FUSE");
   if (e && *e && atoi(e) == 0) return false;
-  return c.patch && c.pre_ln && !c.input_ln && (c.dim % 64) == 0;
+  return c.patch && c.pre_ln && !c.input_ln && !c.fp8 && (c.dim % 64) == 0;
 }
 
 // W' = W.diag(gamma) (bf16), colsum, tbias for one linear layer; `perm` (optional) maps packed row -> source row
@@ -302,6 +304,26 @@ int resolve(vdr_model* m) {
       if (rc) return rc;
     }
   }
+  if (c.fp8) {
+    VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+    const int D = c.dim, F = c.mlp_hidden;
+    const int N1 = c.act == VDR_ACT_SWIGLU ? 2 * F : F;
+    auto quant = [&](const void* wdev, int N, int K, void** q, void** sc) -> int {
+      if (!*q) VDR_TRY(hipMalloc(q, (size_t)N * K + 256), "hipMalloc(fp8 weight)");
+      if (!*sc) VDR_TRY(hipMalloc(sc, mx_scale_bytes(N, K) + 256), "hipMalloc(fp8 weight scales)");
+      VDR_TRY(hipMemset(*sc, 0, mx_scale_bytes(N, K)), "hipMemset(fp8 weight scales)");
+      VDR_TRY(launch_mx_quant(wdev, N, K, K, *q, *sc, nullptr), "mx_quant(weight)");
+      return VDR_OK;
+    };
+    for (int i = 0; i < c.layers; ++i) {
+      LayerW& L = m->layers[i];
+      int rc;
+      if ((rc = quant(L.wqkv, 3 * D, D, &L.qkv_q, &L.qkv_s))) return rc;
+      if ((rc = quant(L.w1, N1, D, &L.w1_q, &L.w1_s))) return rc;
+      if ((rc = quant(L.w2, D, F, &L.w2_q, &L.w2_s))) return rc;
+    }
+    VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
   if (c.window > 0) {
     VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
     const int g = c.img / c.patch;
@@ -323,6 +345,7 @@ struct Carve {
   char *x, *h, *qkv, *o, *u;
   char* hg = nullptr;    // SAM: LN1 output of the global blocks (h holds the windowed, zero-padded order)
   float* rel = nullptr;  // SAM: relative position terms [tokens][heads][2S]
+  char *hs = nullptr, *us = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h and u
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;
   size_t total;
@@ -365,6 +388,10 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
   if (c.window > 0) {
     w.hg = take(Mp * D * 2);
     w.rel = (float*)take(rel_floats * 4 + 256);
+  }
+  if (c.fp8) {
+    w.hs = take(mx_scale_bytes((int64_t)Mp, (int)D));
+    w.us = take(mx_scale_bytes((int64_t)Mp, (int)F));
   }
   w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
   w.stats = (float*)take(Mp * 8);
@@ -525,6 +552,70 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
   const int64_t M = (int64_t)mb * ntok;
   const bool sw = c.act == VDR_ACT_SWIGLU;
   int rc;
+  if (c.fp8) {
+    // BASELINE config 5: qkv / fc1 / fc2 on the block-scaled fp8 MFMA.  LayerNorm writes its output as MX-fp8
+    // (the qkv / fc1 operand), the fc1 epilogue re-quantises the activation to MX-fp8 (the fc2 operand); the
+    // residual stream, attention and the out-projection stay bf16.
+    const int N1 = sw ? 2 * F : F;
+    auto mx_variant = [&](int cls, int N) {
+      static const int forced = env_int("VDR_MX_VARIANT", -1);
+      if (forced >= 0) return forced;
+      if (((M + 127) / 128) * ((N + 255) / 256) < 256) return 2;  // small problem: 128x128 tiles
+      if (cls == VDR_K_GEMM_QKV) return 0;
+      return M >= 16384 ? 0 : 1;  // measured (tools/mx_bench.py): 256x256 tiles win at ViT-g's M = 8224
+    };
+    auto gemm_mx = [&](int cls, const void* aq, const void* as, const void* wq, const void* wsc, const float* bias,
+                       const void* resid, const float* gamma, void* C, void* cs, int N, int K, int ldc, int epi) -> int {
+      GemmArgs g{};
+      g.A = aq;
+      g.a_scale = as;
+      g.W = wq;
+      g.w_scale = wsc;
+      g.bias = bias;
+      g.resid = resid;
+      g.gamma = gamma;
+      g.C = C;
+      g.c_scale = cs;
+      g.M = M;
+      g.N = N;
+      g.K = K;
+      g.lda = K;
+      g.ldw = K;
+      g.ldc = ldc;
+      g.ldr = ldc;
+      g.omap = identity_map();
+      const double outb = cs ? 1.0 : 2.0;
+      Scope sc(m, s, cls, 2.0 * M * N * K, (double)M * K + (double)N * K + (double)M * ldc * (resid ? 2 * outb : outb));
+      VDR_TRY(launch_gemm_mx(g, epi, mx_variant(cls, N), s), "gemm_mx");
+      return VDR_OK;
+    };
+    for (int i = 0; i < c.layers; ++i) {
+      const LayerW& L = m->layers[i];
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
+        VDR_TRY(launch_ln_mx(w.x, L.n1w, L.n1b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
+      }
+      if ((rc = gemm_mx(VDR_K_GEMM_QKV, w.h, w.hs, L.qkv_q, L.qkv_s, L.bqkv, nullptr, nullptr, w.qkv, nullptr, 3 * D, D,
+                        3 * D, EPI_BIAS)))
+        return rc;
+      {
+        Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
+        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
+      }
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
+        VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
+      }
+      if ((rc = gemm_mx(VDR_K_GEMM_FC1, w.h, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, N1, D, F,
+                        sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+        return rc;
+      if ((rc = gemm_mx(VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, w.x, L.ls2, w.x, nullptr, D, F, D, EPI_BIAS_RESID)))
+        return rc;
+    }
+    return VDR_OK;
+  }
   if (c.pre_ln && m->ln_fuse) {
     // LayerNorm never materialised: producers leave (sum, sumsq) partials, a tiny kernel turns them into
     // (mean, rstd), the consuming GEMM applies them in its epilogue (weights pre-multiplied by gamma).
@@ -794,6 +885,8 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
     return fail(nullptr, VDR_ERR_UNSUPPORTED, "token models carry no learned pos_embed");
   }
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
+  if (c.fp8 && (!c.pre_ln || c.window > 0))
+    return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models without windowed attention only");
   if (c.window > 0) {
     const int g = c.patch ? c.img / c.patch : 0;
     auto side_ok = [](int v) { return v == 4 || v == 7 || v == 10 || v == 14 || v == 64; };
@@ -832,6 +925,8 @@ void vdr_destroy(vdr_handle h) {
   for (auto& L : h->layers) {
     if (L.wqkv_f) hipFree(L.wqkv_f);
     if (L.reltab) hipFree(L.reltab);
+    for (void* q : {L.qkv_q, L.qkv_s, L.w1_q, L.w1_s, L.w2_q, L.w2_s})
+      if (q) hipFree(q);
     if (L.w1_f) hipFree(L.w1_f);
     if (L.sqkv) hipFree(L.sqkv);
     if (L.tqkv) hipFree(L.tqkv);

@@ -13,7 +13,9 @@ struct RowMap {
 };
 static inline RowMap identity_map() { return RowMap{1 << 30, 0, 0}; }
 
-enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_SWIGLU = 3, EPI_PATCH = 4 };
+enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_SWIGLU = 3, EPI_PATCH = 4,
+                // internal to gemm_mx.hip: GELU / SwiGLU with the output re-quantised to MX-fp8
+                EPI_BIAS_GELU_MX = 5, EPI_SWIGLU_MX = 6 };
 
 struct GemmArgs {
   const void* A;      // [M, K] bf16, row stride lda

@@ -33,6 +33,7 @@ class VdrConfig:
     window: int = 0            # SAM: windowed attention side (14) + decomposed rel-pos
     global_blocks: tuple = ()  # SAM: blocks with global attention (2, 5, 8, 11)
     neck_chans: int = 0        # SAM: conv neck output channels (256)
+    fp8: bool = False          # qkv / fc1 / fc2 weights and their activations as MX-fp8 (BASELINE config 5)
 
     @property
     def n_patches(self):
@@ -52,6 +53,7 @@ class VdrConfig:
         c.streams = int(self.streams)
         c.window, c.neck_chans = int(self.window), int(self.neck_chans)
         c.global_mask = sum(1 << int(i) for i in self.global_blocks)
+        c.fp8 = int(self.fp8)
         return c
 
 

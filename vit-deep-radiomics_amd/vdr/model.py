@@ -88,13 +88,17 @@ class VitDescriptorModel:
         return self.image_encoder(x) if self.cfg.window > 0 else self.forward_features(x)
 
 
-def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0):
+def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0,
+               fp8: bool = False):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
-    torch.load(weights_only=True).  weights: the same dict passed directly."""
+    torch.load(weights_only=True).  weights: the same dict passed directly.
+    fp8=True keeps the qkv / fc1 / fc2 weights as MX-fp8 and runs them on the block-scaled fp8 MFMA
+    (BASELINE config 5; pre-LN models)."""
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
-    cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams})
+    cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams,
+                       "fp8": bool(fp8) or ARCHS[model_name].fp8})
     if weights is None:
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
