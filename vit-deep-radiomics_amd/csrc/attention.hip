@@ -29,7 +29,54 @@ struct AttnK {
   int qt_per_block;  // query tiles handled by one workgroup
   int n_chunks;      // key chunks of NT*32 keys
   int abl;           // diagnostic: 1 = no compute, 2 = no staging after the first item
+  uint8_t* o_scale;  // non-null: `out` is an MX-fp8 payload [tokens][heads*64] and this its e8m0 scale array
+  int64_t os_rows;   //           (mx.hip layout: [heads*2 blocks][os_rows], rows paired inside 64-row groups)
 };
+
+// One output row (token `grow`, head `hd`): this lane holds dims nd*32 + 8g + 4hh + e of it, its partner lane
+// (xor 32) the other half of each 32-dim block.  bf16 store, or -- fp8 path, operand of the MX out-projection --
+// one e8m0 scale per 32-dim block agreed with the partner lane and 4-byte e4m3 stores.
+VDR_DEV void attn_store_row(const AttnK& p, const f32x16 (&o)[2], float inv, bool ok, int64_t grow, int hd, int hh) {
+  if (p.o_scale) {
+    uint8_t* dst = reinterpret_cast<uint8_t*>(p.out) + grow * p.ld_out + hd * 64;
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd) {
+      float amax = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(o[nd][e] * inv));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const float t = amax * (1.0f / 448.0f);
+      const uint32_t tb = __float_as_uint(t);
+      int ex = (int)((tb >> 23) & 255) - 127 + ((tb & 0x7fffff) ? 1 : 0);
+      ex = ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+      const float qs = inv * __uint_as_float((uint32_t)(127 - ex) << 23);
+      if (ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(o[nd][4 * g] * qs, o[nd][4 * g + 1] * qs, w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(o[nd][4 * g + 2] * qs, o[nd][4 * g + 3] * qs, w, true);
+          *reinterpret_cast<int*>(dst + nd * 32 + 8 * g + 4 * hh) = w;
+        }
+        if (hh == nd)
+          p.o_scale[(int64_t)(hd * 2 + nd) * p.os_rows + (grow & ~(int64_t)63) + 2 * (grow & 31) + ((grow >> 5) & 1)] =
+              (uint8_t)(ex + 127);
+      }
+    }
+    return;
+  }
+  if (!ok) return;
+  bf16_t* dst = p.out + grow * p.ld_out + hd * 64;
+#pragma unroll
+  for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
+      *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
+    }
+}
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
@@ -52,7 +99,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
-  bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
 
   const int nqt = (p.seq + 31) >> 5;
   const int qt_begin = blockIdx.y * p.qt_per_block;
@@ -202,18 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
-    if (q < p.seq) {
-      bf16_t* dst = ob + (int64_t)q * p.ld_out;
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
-          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
-        }
-    }
+    attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
   };
 
   if (p.n_chunks == 1) {
@@ -336,7 +371,6 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
   auto compute_tile = [&](int item, int next_item, int qt, const char* buf, bf16x8 (&qf)[4]) {
     const int b = item / p.heads;
     const int hd = item - b * p.heads;
-    bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
     const char* sK = buf + l31 * 128;
     const char* sVt = buf + KEYS * 128 + l31 * VT_STRIDE + hh * 8;
     int kch[4];
@@ -428,18 +462,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
-    if (q < p.seq) {
-      bf16_t* dst = ob + (int64_t)q * p.ld_out;
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
-          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
-        }
-    }
+    attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
   };
 
   int item = blockIdx.x;
@@ -504,13 +527,15 @@ static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
 }
 
 hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
-                            hipStream_t s) {
+                            hipStream_t s, void* out_scale) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return hipErrorInvalidValue;
   AttnK k;
   k.abl = variant / 10;
   variant %= 10;
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
+  k.o_scale = (uint8_t*)out_scale;
+  k.os_rows = mx_rows_pad((int64_t)batch * seq);
   k.seq = seq;
   k.heads = heads;
   k.ld_qkv = (int64_t)3 * heads * 64;

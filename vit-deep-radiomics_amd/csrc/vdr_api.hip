@@ -51,6 +51,7 @@ struct LayerW {
   void* reltab = nullptr;  // both tables packed as one [relpos_npad(S)][64] bf16 GEMM operand
   void *wqkv_f = nullptr, *w1_f = nullptr;
   // fp8 path: MX-fp8 copies (payload, scales) of the qkv / fc1 (w12) / fc2 (w3) weights
+  void *proj_q = nullptr, *proj_s = nullptr;
   void *qkv_q = nullptr, *qkv_s = nullptr, *w1_q = nullptr, *w1_s = nullptr, *w2_q = nullptr, *w2_s = nullptr;
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
@@ -319,6 +320,7 @@ int resolve(vdr_model* m) {
       LayerW& L = m->layers[i];
       int rc;
       if ((rc = quant(L.wqkv, 3 * D, D, &L.qkv_q, &L.qkv_s))) return rc;
+      if ((rc = quant(L.wproj, D, D, &L.proj_q, &L.proj_s))) return rc;
       if ((rc = quant(L.w1, N1, D, &L.w1_q, &L.w1_s))) return rc;
       if ((rc = quant(L.w2, D, F, &L.w2_q, &L.w2_s))) return rc;
     }
@@ -345,7 +347,7 @@ struct Carve {
   char *x, *h, *qkv, *o, *u;
   char* hg = nullptr;    // SAM: LN1 output of the global blocks (h holds the windowed, zero-padded order)
   float* rel = nullptr;  // SAM: relative position terms [tokens][heads][2S]
-  char *hs = nullptr, *us = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h and u
+  char *hs = nullptr, *us = nullptr, *os = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h, u, o
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;
   size_t total;
@@ -392,6 +394,7 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
   if (c.fp8) {
     w.hs = take(mx_scale_bytes((int64_t)Mp, (int)D));
     w.us = take(mx_scale_bytes((int64_t)Mp, (int)F));
+    w.os = take(mx_scale_bytes((int64_t)Mp, (int)D));
   }
   w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
   w.stats = (float*)take(Mp * 8);
@@ -554,8 +557,8 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
   int rc;
   if (c.fp8) {
     // BASELINE config 5: qkv / fc1 / fc2 on the block-scaled fp8 MFMA.  LayerNorm writes its output as MX-fp8
-    // (the qkv / fc1 operand), the fc1 epilogue re-quantises the activation to MX-fp8 (the fc2 operand); the
-    // residual stream, attention and the out-projection stay bf16.
+    // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
+    // operands); the residual stream and the attention arithmetic stay bf16 / fp32.
     const int N1 = sw ? 2 * F : F;
     auto mx_variant = [&](int cls, int N) {
       static const int forced = env_int("VDR_MX_VARIANT", -1);
@@ -601,9 +604,11 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
-        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, w.os), "attention");
       }
-      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
+      if ((rc = gemm_mx(VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, D, D, D,
+                        EPI_BIAS_RESID)))
+        return rc;
       {
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
@@ -925,7 +930,7 @@ void vdr_destroy(vdr_handle h) {
   for (auto& L : h->layers) {
     if (L.wqkv_f) hipFree(L.wqkv_f);
     if (L.reltab) hipFree(L.reltab);
-    for (void* q : {L.qkv_q, L.qkv_s, L.w1_q, L.w1_s, L.w2_q, L.w2_s})
+    for (void* q : {L.qkv_q, L.qkv_s, L.proj_q, L.proj_s, L.w1_q, L.w1_s, L.w2_q, L.w2_s})
       if (q) hipFree(q);
     if (L.w1_f) hipFree(L.w1_f);
     if (L.sqkv) hipFree(L.sqkv);

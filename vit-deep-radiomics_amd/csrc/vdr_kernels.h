@@ -73,8 +73,10 @@ struct LnArgs {
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 
+//   out_scale != NULL: `out` is written as MX-fp8 (payload [batch*seq][heads*64] bytes + e8m0 scales), the
+//   operand of the fp8 out-projection
 hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
-                            hipStream_t s);
+                            hipStream_t s, void* out_scale = nullptr);
 
 // SAM / MedSAM decomposed relative position bias (attention_relpos.hip)
 //   rel [tokens][heads][2S] fp32 = (q . Rh[qh - kh + S-1], q . Rw[qw - kw + S-1]); qkv rows are S*S-token
