@@ -52,7 +52,7 @@ typedef enum {
   VDR_ERR_UNSUPPORTED = -7   /* config outside what the kernels cover       */
 } vdr_status;
 
-typedef enum { VDR_F32 = 0, VDR_BF16 = 1 } vdr_dtype;
+typedef enum { VDR_F32 = 0, VDR_BF16 = 1, VDR_F64 = 2, VDR_I16 = 3 } vdr_dtype; /* F64 / I16: pre-processing inputs only */
 
 typedef enum { VDR_ACT_GELU = 0, /* exact erf GELU: models_archs.py:133, timm/DINOv2 Mlp */
                VDR_ACT_SWIGLU = 1 /* DINOv2 ViT-g SwiGLUFFN (w12 / w3)                   */
@@ -206,6 +206,32 @@ int vdr_op_layernorm_mx(const void* x, const float* gamma, const float* beta, fl
 int vdr_op_linear_mx(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
                      const void* resid, const float* gamma, void* y, void* yscales, int64_t M, int N, int K,
                      int epilogue, int variant, void* stream);
+
+/* ---- pre/post-processing either side of the encoder --------------------------
+ * What the reference does per slice on the CPU with numpy / skimage; all pointers are device pointers. */
+
+/* prepare_image (tfds_dense_descriptor.py:30-48) for a batch of slices: gray2rgb, skimage.transform.resize
+ * (order 1, mode 'reflect', anti-aliasing Gaussian when down-scaling, float64 arithmetic), HWC -> CHW; the
+ * flips of flip_image (:305-324) are folded in.
+ *   src        fp32 (src_dtype VDR_F32) or fp64 (VDR_F64) image(s) with ELEMENT strides (stride_b, stride_y,
+ *              stride_x, stride_c): the slices of an (H, W, S[, C]) volume are a batch as they lie
+ *   channels   1 (replicated to 3, target side 1024 in the reference) or 3 (target side 896)
+ *   flip       0 none, 1 'horizontal' (x reversed), 2 'vertical' (y reversed)
+ *   out        [batch, 3, out_side, out_side] fp32 or bf16 (out_dtype)
+ *   scratch    device scratch of vdr_prepare_scratch_bytes(...) bytes (0 when nothing is down-scaled) */
+size_t vdr_prepare_scratch_bytes(int batch, int h, int w, int channels, int out_side);
+int vdr_op_prepare_image(const void* src, int src_dtype, int batch, int h, int w, int channels, int64_t stride_b,
+                         int64_t stride_y, int64_t stride_x, int64_t stride_c, int flip, int out_side, void* out,
+                         int out_dtype, void* scratch, void* stream);
+/* apply_window_ct (tfds_dense_descriptor.py:287-302, windowing_ct :204-237): clip((ct - (L - W/2)) / W, 0, 1).
+ *   ct fp32 (VDR_F32) or int16 (VDR_I16), n elements -> out fp32 */
+int vdr_op_window_ct(const void* ct, int in_dtype, int64_t n, double width, double level, float* out, void* stream);
+/* hu_to_rgb_vectorized (visualization_utils.py:128-186): HU -> uint8 RGB [n, 3].  hu fp32 / int16 / fp64. */
+int vdr_op_hu_to_rgb(const void* hu, int in_dtype, int64_t n, void* rgb, void* stream);
+/* crop_image / extract_roi (visualization_utils.py:93-125) of channel-last maps:
+ *   src fp32 [batch, H, W, C] -> dst fp32 [batch, crop_h, crop_w, C], window origin (y0, x0), fully inside */
+int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C, int y0, int x0, int crop_h,
+                    int crop_w, void* stream);
 
 /* F.scaled_dot_product_attention over a packed qkv activation — the core of
  * nn.MultiheadAttention (models_archs.py:130) / Attention.forward of the ViTs.

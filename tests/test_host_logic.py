@@ -89,3 +89,22 @@ def test_world2_gloo_allgather_reassembles_rows_bitwise(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_pipeline_roi_host_logic_matches_reference_goldens(golden_dir):
+    """vdr.pipeline's host-side box maths (extract_coords / extract_roi / crop_image) vs the reference's own
+    functions (tests/golden/prep_roi.npz)."""
+    import os
+    import numpy as np
+    from vdr import pipeline
+
+    r = np.load(os.path.join(golden_dir, "prep_roi.npz"))
+    for i in range(int(r["n_cases"])):
+        m, f = r[f"c{i}_mask"], r[f"c{i}_feat"]
+        for mg in (1, 2):
+            assert tuple(r[f"c{i}_coords_m{mg}"]) == pipeline.extract_coords(m, mg)
+        assert np.array_equal(pipeline.extract_roi(f, m), r[f"c{i}_roi_feat"])
+        assert np.array_equal(pipeline.extract_roi(m, m), r[f"c{i}_roi_mask"])
+        assert np.array_equal(pipeline.crop_image(f, *[int(v) for v in r[f"c{i}_crop_args"]]), r[f"c{i}_crop"])
+    with __import__("pytest").raises(ValueError):
+        pipeline.extract_coords(np.zeros((4, 4), dtype=bool), 1)

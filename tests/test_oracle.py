@@ -129,3 +129,30 @@ def test_mx_fp8_quantiser_matches_golden_table(golden_dir):
     d = mx.mx_dequantize(q, e)
     blockmax = x.reshape(x.shape[0], -1, 32).abs().amax(-1, keepdim=True).expand(-1, -1, 32).reshape(x.shape)
     assert bool(((d - x).abs() <= blockmax * 2.0 ** -4 * 1.0001 + 1e-30).all())
+
+
+def test_prep_oracle_matches_reference_goldens(golden_dir):
+    """oracle/prep_oracle.py vs vectors produced by the reference's own visualization_utils functions and the
+    skimage calls of prepare_image (tests/golden/make_golden_prep.py)."""
+    from oracle import prep_oracle as po
+
+    g = np.load(os.path.join(golden_dir, "prep_resize.npz"))
+    for name in list(g["names"]) + ["up_gray64"]:
+        x, want = g[name + "_in"], g[name + "_out"]
+        got = po.prepare_image(x, side=want.shape[-1])
+        assert float(np.abs(got.astype(np.float64) - want).max()) <= (1e-5 if x.ndim == 3 else 1.2e-7), name
+    h = np.load(os.path.join(golden_dir, "prep_hu.npz"))
+    for a, b in (("hu", "rgb"), ("hu_i16", "rgb_i16"), ("hu_f32", "rgb_f32")):
+        assert np.array_equal(po.hu_to_rgb(h[a]), h[b]), a
+    r = np.load(os.path.join(golden_dir, "prep_roi.npz"))
+    for i in range(int(r["n_cases"])):
+        m, f = r[f"c{i}_mask"], r[f"c{i}_feat"]
+        for mg in (1, 2):
+            assert tuple(r[f"c{i}_coords_m{mg}"]) == po.extract_coords(m, mg)
+        assert np.array_equal(po.extract_roi(f, m), r[f"c{i}_roi_feat"])
+        assert np.array_equal(po.extract_roi(m, m), r[f"c{i}_roi_mask"])
+        assert np.array_equal(po.crop_image(f, *[int(v) for v in r[f"c{i}_crop_args"]]), r[f"c{i}_crop"])
+    wv = np.load(os.path.join(golden_dir, "prep_window.npz"))
+    for tag, (w, l) in {"w800_l40": (800, 40), "w1500_lm600": (1500, -600), "w350_l50": (350, 50)}.items():
+        for nm in ("i16", "f32"):
+            assert np.array_equal(po.apply_window_ct(wv["ct_" + nm], w, l), wv[f"{tag}_{nm}"])

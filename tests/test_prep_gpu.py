@@ -1,0 +1,119 @@
+"""GPU pre/post-processing against golden vectors made from the reference's own
+numpy helpers and the skimage calls of prepare_image (tests/golden/make_golden_prep.py), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prep_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_prepare_image_matches_skimage_golden(golden_dir):
+    """gray2rgb + resize(order 1, 'reflect', anti-aliasing) + CHW: <= 2 float32 ulp for gray inputs, 1e-5 for the
+    3-channel path (skimage's own multichannel warp keeps float32 intermediates)."""
+    from vdr import prep
+    g = _load(golden_dir, "prep_resize.npz")
+    for name in list(g["names"]) + ["up_gray64"]:
+        x, want = g[name + "_in"], g[name + "_out"]
+        side = want.shape[-1]
+        vol = torch.from_numpy(x).unsqueeze(2)
+        got = prep.prepare_slices(vol, side=side)[0].cpu().numpy()
+        tol = 1e-5 if x.ndim == 3 else 3e-7
+        err = float(np.abs(got.astype(np.float64) - want).max())
+        assert got.shape == want.shape and err <= tol, (name, err)
+
+
+def test_prepare_slices_volume_flips_bf16():
+    """all slices of a strided (H, W, S) volume in one launch == slice by slice; flips folded into the gather ==
+    flipping first (flip_image, tfds_dense_descriptor.py:305-324); bf16 output = rounded fp32 output."""
+    from vdr import prep
+    rng = np.random.default_rng(5)
+    vol = rng.random((45, 38, 7)).astype(np.float32)
+    ref = np.stack([po.prepare_image(vol[:, :, i], side=96) for i in range(7)])
+    got = prep.prepare_slices(vol, side=96)
+    assert float(np.abs(got.cpu().numpy() - ref).max()) <= 3e-7
+    for flip, fl in (("horizontal", vol[:, ::-1]), ("vertical", vol[::-1])):
+        a = prep.prepare_slices(vol, side=96, flip=flip).cpu().numpy()
+        b = np.stack([po.prepare_image(np.ascontiguousarray(fl[:, :, i]), side=96) for i in range(7)])
+        assert float(np.abs(a - b).max()) <= 3e-7, flip
+    bf = prep.prepare_slices(vol, side=96, out_dtype=torch.bfloat16)
+    assert torch.equal(bf, got.to(torch.bfloat16))
+    # colour volume (H, W, S, 3) and a down-scaled one (anti-aliasing path)
+    col = rng.random((70, 66, 3, 3)).astype(np.float32)
+    ref = np.stack([po.prepare_image(col[:, :, i], side=40) for i in range(3)])
+    got = prep.prepare_slices(col, side=40).cpu().numpy()
+    assert float(np.abs(got - ref).max()) <= 2e-6
+    # the reference's default sides
+    assert prep.prepare_image(vol[:, :, 0]).shape == (1, 3, 1024, 1024)
+    assert prep.prepare_image(col[:, :, 0]).shape == (1, 3, 896, 896)
+
+
+def test_window_ct_and_hu_colormap_bit_exact(golden_dir):
+    from vdr import prep
+    g = _load(golden_dir, "prep_window.npz")
+    for tag, (w, l) in {"w800_l40": (800, 40), "w1500_lm600": (1500, -600), "w350_l50": (350, 50)}.items():
+        got = prep.apply_window_ct(g["ct_f32"], w, l).cpu().numpy()
+        assert np.array_equal(got, g[f"{tag}_f32"]), tag                      # float32 in: numpy computes in float32
+        got = prep.apply_window_ct(g["ct_i16"], w, l).cpu().numpy()
+        assert np.array_equal(got, g[f"{tag}_i16"].astype(np.float32)), tag   # int16 in: float64, stored as fp32
+    h = _load(golden_dir, "prep_hu.npz")
+    for a, b in (("hu", "rgb"), ("hu_i16", "rgb_i16"), ("hu_f32", "rgb_f32")):
+        got = prep.hu_to_rgb_vectorized(h[a]).cpu().numpy()
+        assert got.dtype == np.uint8 and np.array_equal(got, h[b]), a
+
+
+def test_crop_maps_matches_reference_roi(golden_dir):
+    """extract_roi / crop_image of a feature map on the device == the reference's numpy crops."""
+    from vdr import pipeline
+    g = _load(golden_dir, "prep_roi.npz")
+    for i in range(int(g["n_cases"])):
+        mask, feat = g[f"c{i}_mask"], g[f"c{i}_feat"]
+        maps = torch.from_numpy(np.stack([feat, feat * 2])).cuda()
+        got = pipeline.crop_maps(maps, pipeline.roi_box(feat.shape[0:2], mask)).cpu().numpy()
+        assert np.array_equal(got[0], g[f"c{i}_roi_feat"]) and np.array_equal(got[1], g[f"c{i}_roi_feat"] * 2), i
+        got = pipeline.crop_maps(maps, tuple(int(v) for v in g[f"c{i}_crop_args"])).cpu().numpy()
+        assert np.array_equal(got[0], g[f"c{i}_crop"]), i
+
+
+def test_generate_features_batched_pipeline_vs_oracle():
+    """The per-slice hot loop (tfds_dense_descriptor.py:242-284) as one batched GPU pipeline on a small SAM
+    geometry: same list lengths, same crop shapes, feature maps within the bf16 gate of the oracle pipeline
+    (numpy prepare_image -> fp32 SAM oracle -> extract_roi)."""
+    import vdr
+    from vdr import pipeline
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64)
+    w = so.make_weights(cfg, seed=21)
+    vc = vdr.VdrConfig(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, has_cls=False, window=7,
+                       global_blocks=(1,), neck_chans=64)
+    model = vdr.VitDescriptorModel(vc, w, "medsam", torch.device("cuda"))
+    model.model_name = "medsam"
+    rng = np.random.default_rng(8)
+    H, W, S = 72, 80, 5
+    img = rng.random((H, W, S)).astype(np.float32)
+    mask = np.zeros((H, W, S), dtype=bool)
+    mask[30:41, 36:50, 1:4] = True
+    feats, masks = pipeline.generate_features(model, img, mask, max_batch=3)
+    assert len(feats) == S and len(masks) == S
+    # oracle pipeline, slice by slice, following the reference loop
+    bigger = mask.sum(-1) > 0
+    xmin, ymin, xmax, ymax = po.extract_coords(bigger, 2)
+    cs = max(xmax - xmin, ymax - ymin) * 2
+    xm, ym = int(xmin + (xmax - xmin) / 2), int(ymin + (ymax - ymin) / 2)
+    box = (xm - cs, ym - cs, xm + cs, ym + cs)
+    img_c, mask_c, big_c = po.crop_image(img, *box), po.crop_image(mask, *box), po.crop_image(bigger, *box)
+    for i in range(S):
+        x = torch.from_numpy(po.prepare_image(img_c[:, :, i], side=224))[None]
+        f = so.sam_forward(cfg, w, x)["out"][0].permute(1, 2, 0).numpy()
+        want = po.extract_roi(f, big_c)
+        assert feats[i].shape == want.shape and feats[i].dtype == np.float32
+        rel = np.linalg.norm(feats[i] - want) / np.linalg.norm(want)
+        assert rel < 2e-2, (i, rel)
+        assert np.array_equal(masks[i], po.extract_roi(mask_c[:, :, i] > 0, big_c))

@@ -1257,6 +1257,55 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
   return VDR_OK;
 }
 
+size_t vdr_prepare_scratch_bytes(int batch, int h, int w, int channels, int out_side) {
+  if (batch <= 0 || h <= 0 || w <= 0 || channels <= 0 || out_side <= 0) return 0;
+  return prepare_scratch_bytes(batch, h, w, channels, out_side);
+}
+
+int vdr_op_prepare_image(const void* src, int src_dtype, int batch, int h, int w, int channels, int64_t stride_b,
+                         int64_t stride_y, int64_t stride_x, int64_t stride_c, int flip, int out_side, void* out,
+                         int out_dtype, void* scratch, void* stream) {
+  if (!src || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (src_dtype != VDR_F32 && src_dtype != VDR_F64) return fail(nullptr, VDR_ERR_UNSUPPORTED, "prepare_image: fp32 or fp64 input");
+  if (out_dtype != VDR_F32 && out_dtype != VDR_BF16) return fail(nullptr, VDR_ERR_UNSUPPORTED, "prepare_image: fp32 or bf16 output");
+  if (prepare_scratch_bytes(batch, h, w, channels, out_side) && !scratch)
+    return fail(nullptr, VDR_ERR_INVALID, "prepare_image: down-scaling needs the scratch buffer");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_prepare(src, src_dtype == VDR_F32, batch, h, w, channels, stride_b, stride_y, stride_x, stride_c, flip, out_side,
+                        out, out_dtype == VDR_BF16, (float*)scratch, (hipStream_t)stream),
+         "prepare_image");
+  return VDR_OK;
+}
+
+int vdr_op_window_ct(const void* ct, int in_dtype, int64_t n, double width, double level, float* out, void* stream) {
+  if (!ct || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (in_dtype != VDR_F32 && in_dtype != VDR_I16) return fail(nullptr, VDR_ERR_UNSUPPORTED, "window_ct: fp32 or int16 input");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_window_ct(ct, in_dtype == VDR_I16, n, width, level, out, (hipStream_t)stream), "window_ct");
+  return VDR_OK;
+}
+
+int vdr_op_hu_to_rgb(const void* hu, int in_dtype, int64_t n, void* rgb, void* stream) {
+  if (!hu || !rgb) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  const int dt = in_dtype == VDR_F32 ? 0 : in_dtype == VDR_I16 ? 1 : in_dtype == VDR_F64 ? 2 : -1;
+  if (dt < 0) return fail(nullptr, VDR_ERR_UNSUPPORTED, "hu_to_rgb: fp32, int16 or fp64 input");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_hu_to_rgb(hu, dt, n, rgb, (hipStream_t)stream), "hu_to_rgb");
+  return VDR_OK;
+}
+
+int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C, int y0, int x0, int crop_h, int crop_w,
+                    void* stream) {
+  if (!src || !dst) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_crop_hwc(src, dst, batch, H, W, C, y0, x0, crop_h, crop_w, (hipStream_t)stream), "crop_hwc");
+  return VDR_OK;
+}
+
 size_t vdr_mx_scale_bytes(int64_t rows, int K) { return rows > 0 && K > 0 ? mx_scale_bytes(rows, K) : 0; }
 
 int vdr_op_mx_quantize(const void* x, int64_t rows, int K, void* q, void* scales, void* stream) {

@@ -95,6 +95,15 @@ hipError_t launch_ln_mx(const void* x, const float* gamma, const float* beta, fl
 //   C = epi(A . W^T) with MX operands; variant 0: 128x256 tile / 8 waves, 1: 256x256 / 16 waves, 2: 128x128 / 4 waves
 hipError_t launch_gemm_mx(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 
+// ---- pre/post-processing (prep.hip) --------------------------------------------------------------------
+size_t prepare_scratch_bytes(int batch, int h, int w, int ch, int out_side);
+hipError_t launch_prepare(const void* src, int src_f32, int batch, int h, int w, int ch, int64_t sb, int64_t sy, int64_t sx,
+                          int64_t sc, int flip, int out_side, void* out, int out_bf16, float* scratch, hipStream_t s);
+hipError_t launch_window_ct(const void* ct, int in_i16, int64_t n, double width, double level, float* out, hipStream_t s);
+hipError_t launch_hu_to_rgb(const void* hu, int dtype, int64_t n, void* rgb, hipStream_t s);
+hipError_t launch_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C, int y0, int x0, int ch, int cw,
+                           hipStream_t s);
+
 static inline int relpos_npad(int S) { return 2 * ((2 * S - 1 + 31) / 32 * 32); }
 hipError_t launch_relpos_pack(const float* rel_h, const float* rel_w, void* table, int S, hipStream_t s);
 //   softmax(q k^T / 8 + T[qh - kh + S-1] + T[Npad/2 + qw - kw + S-1]) v per (window, head);

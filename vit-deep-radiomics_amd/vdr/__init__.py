@@ -8,3 +8,4 @@ from ._lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU, OUT_CLS,
 from .engine import Engine, VdrConfig  # noqa: F401
 from .model import (ARCHS, TransformerNoduleClassifier, VitDescriptorModel, extract_dense, get_dense_descriptor,  # noqa: F401
                     load_model)
+from . import pipeline, prep  # noqa: F401,E402

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdr.so")
 
-VDR_F32, VDR_BF16 = 0, 1
+VDR_F32, VDR_BF16, VDR_F64, VDR_I16 = 0, 1, 2, 3
 ACT_GELU, ACT_SWIGLU = 0, 1
 OUT_CLS, OUT_DENSE, OUT_PATCH_EMBED, OUT_TOKENS, OUT_ENCODER = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
@@ -46,6 +46,11 @@ SYMBOLS = {
     "vdr_forward_tokens": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, C.c_size_t, _P]),
     "vdr_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P]),
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "vdr_prepare_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "vdr_op_prepare_image": (_I, [_P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _I, _P, _P]),
+    "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),
+    "vdr_op_hu_to_rgb": (_I, [_P, _I, _L, _P, _P]),
+    "vdr_op_crop_hwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vdr_mx_scale_bytes": (C.c_size_t, [_L, _I]),
     "vdr_op_mx_quantize": (_I, [_P, _L, _I, _P, _P, _P]),
     "vdr_op_mx_dequantize": (_I, [_P, _P, _L, _I, _P, _P]),

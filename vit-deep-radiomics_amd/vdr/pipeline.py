@@ -1,0 +1,133 @@
+"""Batched slice pipeline around the encoder: the reference's per-slice hot loop
+`generate_features` (src/tfds_dense_descriptor.py:242-284) with every slice of a volume in one batch, the ROI
+maths of src/visualization_utils.py:93-125, and the HDF5 layout `save_features` (:142-165) writes, so
+`train_models.py:147-157` reads the files unchanged.
+
+Host-side integer logic (boxes, clamping) is restated here; pixels only move on the GPU (prep.prepare_slices ->
+encoder -> vdr_op_crop_hwc) and come back once per volume, already cropped to the nodule box.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import prep
+
+
+# ---- visualization_utils.py:93-125 ------------------------------------------------------------------------
+def crop_box(shape_hw, xmin, ymin, xmax, ymax):
+    """crop_image's clamping: the (y0, y1, x0, x1) slice bounds it applies to an array of spatial shape shape_hw."""
+    h, w = shape_hw
+    y0, y1 = [max(0, min(int(v), h)) for v in (ymin, ymax)]
+    x0, x1 = [max(0, min(int(v), w)) for v in (xmin, xmax)]
+    return y0, y1, x0, x1
+
+
+def crop_image(img, xmin, ymin, xmax, ymax):
+    y0, y1, x0, x1 = crop_box(img.shape[0:2], xmin, ymin, xmax, ymax)
+    return img[y0:y1, x0:x1]
+
+
+def extract_coords(mask, margin):
+    """Box of a boolean mask; the reference's margins are asymmetric (ymin - m, xmin + m, ymax - m, xmax + m)."""
+    m = np.asarray(mask.cpu() if isinstance(mask, torch.Tensor) else mask)
+    ys, xs = np.nonzero(m)
+    if ys.size == 0:
+        raise ValueError("empty mask")  # the reference raises here too (np.min of an empty array)
+    ymin, xmin = int(ys.min()) - margin, int(xs.min()) + margin
+    ymax, xmax = int(ys.max()) - margin, int(xs.max()) + margin
+    h = max(ymax - ymin, margin)
+    w = max(xmax - xmin, margin)
+    return xmin, ymin, xmin + w, ymin + h
+
+
+def roi_box(img_hw, mask, margin=1):
+    """The box extract_roi crops an array of spatial shape img_hw to (rescaled when img and mask differ in size)."""
+    xmin, ymin, xmax, ymax = extract_coords(mask, margin)
+    mh, mw = mask.shape[0:2]
+    if tuple(img_hw) != (mh, mw):
+        h = img_hw[0] / mh
+        w = img_hw[1] / mw
+        xmin, ymin, xmax, ymax = [int(v) for v in (xmin * w, ymin * h, xmax * w, ymax * h)]
+        hh = max(ymax - ymin, margin)
+        ww = max(xmax - xmin, margin)
+        xmax, ymax = xmin + ww, ymin + hh
+    return xmin, ymin, xmax, ymax
+
+
+def extract_roi(img, mask, margin=1):
+    return crop_image(img, *roi_box(img.shape[0:2], mask, margin))
+
+
+def crop_maps(maps: torch.Tensor, box) -> torch.Tensor:
+    """maps fp32 [B, H, W, C] on the device -> [B, h', w', C] cropped to `box` = (xmin, ymin, xmax, ymax) with
+    crop_image's clamping, by the HIP crop kernel."""
+    lib = L.load()
+    assert maps.is_cuda and maps.dtype == torch.float32 and maps.is_contiguous() and maps.dim() == 4
+    B, H, W, C = maps.shape
+    y0, y1, x0, x1 = crop_box((H, W), *box)
+    if y1 <= y0 or x1 <= x0:
+        return torch.empty((B, max(y1 - y0, 0), max(x1 - x0, 0), C), dtype=torch.float32, device=maps.device)
+    out = torch.empty((B, y1 - y0, x1 - x0, C), dtype=torch.float32, device=maps.device)
+    L.check(lib.vdr_op_crop_hwc(maps.data_ptr(), out.data_ptr(), B, H, W, C, y0, x0, y1 - y0, x1 - x0,
+                                torch.cuda.current_stream(maps.device).cuda_stream))
+    return out
+
+
+# ---- tfds_dense_descriptor.py:242-284 -----------------------------------------------------------------------
+def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
+    """Feature map of every slice, cropped to the nodule region.
+
+    img_3d  (H, W, S) CT/PET volume in [0, 1] ('medsam') or (H, W, S, 3) ('dinov2'); mask_3d (H, W, S) bool.
+    Returns (features_list, mask_list) exactly like the reference: per slice a (h', w', D) float32 array and
+    the (h'', w'') bool mask crop.  All S slices go through prepare -> encoder -> ROI crop in batches of
+    `max_batch` on the GPU; one D2H per batch of the already-cropped maps."""
+    mask_np = np.asarray(mask_3d)
+    bigger_mask = np.sum(mask_np, axis=-1) > 0
+    xmin, ymin, xmax, ymax = extract_coords(bigger_mask, margin=2)
+    crop_size = max(xmax - xmin, ymax - ymin) * 2
+    xmid, ymid = int(xmin + (xmax - xmin) / 2), int(ymin + (ymax - ymin) / 2)
+    box = (xmid - crop_size, ymid - crop_size, xmid + crop_size, ymid + crop_size)
+
+    vol = torch.as_tensor(img_3d)
+    y0, y1, x0, x1 = crop_box(vol.shape[0:2], *box)
+    vol = vol[y0:y1, x0:x1]                      # a view; prepare_slices reads it strided
+    mask_c = mask_np[y0:y1, x0:x1]
+    bigger_c = bigger_mask[y0:y1, x0:x1]
+    vol = vol.to(model.device)
+    if vol.dtype not in (torch.float32, torch.float64):
+        vol = vol.to(torch.float32)
+    S = vol.shape[2]
+    medsam = model.model_name == "medsam"
+    features_list, mask_list = [], []
+    for s0 in range(0, S, max_batch):
+        s1 = min(S, s0 + max_batch)
+        x = prep.prepare_slices(vol[:, :, s0:s1], side=model.cfg.img, flip=flip, device=model.device)
+        if medsam:
+            maps = model.engine.forward(x, L.OUT_ENCODER, torch.float32)          # [b, g, g, C] channel-last
+        else:
+            g = model.cfg.img // model.cfg.patch
+            maps = model.engine.forward(x, L.OUT_PATCH_EMBED, torch.float32).reshape(s1 - s0, g, g, model.cfg.dim)
+        rb = roi_box(maps.shape[1:3], bigger_c)
+        crops = crop_maps(maps.contiguous(), rb).cpu().numpy()
+        for i in range(s1 - s0):
+            features_list.append(crops[i])
+            mask_list.append(extract_roi(mask_c[:, :, s0 + i] > 0, bigger_c))
+    return features_list, mask_list
+
+
+# ---- tfds_dense_descriptor.py:142-165 -----------------------------------------------------------------------
+def save_features(filename, all_features, all_masks, patient_id):
+    """HDF5 layout of the reference: group `patient_id`, datasets `features/{i}` and `masks/{i}`, lzf, one chunk."""
+    try:
+        import h5py
+    except ImportError as e:  # not installed in every image; nothing else can write this format
+        raise RuntimeError("save_features needs h5py (the reference's on-disk format is HDF5)") from e
+    with h5py.File(filename, "a") as h5f:
+        if patient_id in h5f:
+            del h5f[patient_id]
+        grp = h5f.create_group(patient_id)
+        for i, (feature, mask) in enumerate(zip(all_features, all_masks)):
+            grp.create_dataset(f"features/{i}", compression="lzf", data=feature, chunks=feature.shape)
+            grp.create_dataset(f"masks/{i}", compression="lzf", data=mask, chunks=mask.shape)
