@@ -157,6 +157,16 @@ int vdr_forward_tokens(vdr_handle h, const void* tokens, int in_dtype, int batch
                        int out_mode, int out_dtype, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* Variable-length token sequences: the reference feeds one patient's masked-voxel sequence at a
+ * time (batch_size 1, train_models.py:143-182 / conf parameters_models.yaml); here `batch` sequences padded to
+ * max_seq go through one call.  seq_lens: device int32 [batch], 1 <= seq_lens[b] <= max_seq; rows past a
+ * sequence's length may hold anything finite — attention masks them as keys, and the rows of a sequence never
+ * mix with another's.  Outputs as vdr_forward_tokens (VDR_OUT_CLS is what models_archs.py:147 returns); rows of
+ * VDR_OUT_TOKENS / DENSE past a sequence's length are undefined. */
+int vdr_forward_tokens_varlen(vdr_handle h, const void* tokens, int in_dtype, int batch, int max_seq,
+                              const int32_t* seq_lens, void* out, int out_mode, int out_dtype, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- single operators (the torch ops the reference invokes underneath R2/R3) ------------ */
 /* Exposed so that each HIP kernel is parity-tested against its torch op through
  * this ABI (tests/test_ops_gpu.py).  All pointers are device pointers. */

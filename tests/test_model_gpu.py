@@ -296,6 +296,42 @@ def test_golden_reference_class_tokens(golden_dir, tag):
     assert err < 3e-2, f"logits max abs err {err}"
 
 
+@pytest.mark.parametrize("dims,lens", [((64, 1, 2, 128), [5, 1, 17, 9]),
+                                       ((256, 4, 2, 1024), [37, 200, 1, 129, 64, 200]),     # the reference's configured dims
+                                       ((192, 3, 2, 768), [300, 20, 513, 64])])              # > 288 tokens: online softmax
+def test_variable_length_sequences_match_one_at_a_time(dims, lens):
+    """the reference runs its masked-voxel sequences with batch_size 1 because they differ in
+    length; padded to the longest and run in ONE call (per-sequence key masking) every CLS row must equal the
+    oracle's result for that sequence alone, and the GPU's own one-at-a-time result within kernel-variant noise."""
+    import vdr
+    dim, heads, layers, ffn = dims
+    cfg = vo.postln_cfg(dim, heads, layers, ffn)
+    w = vo.make_weights(cfg, seed=13, scale=0.05)
+    e = _engine(cfg, w)
+    S = max(lens)
+    seqs = [vo.make_tokens(1, n, dim, seed=100 + i)[0] for i, n in enumerate(lens)]
+    pad = torch.full((len(lens), S, dim), 3.0)  # non-zero padding: it must not leak into any valid row
+    for i, t in enumerate(seqs):
+        pad[i, : t.shape[0]] = t
+    got = e.forward_tokens(pad.cuda(), vdr.OUT_CLS, lengths=lens).float().cpu()
+    for i, t in enumerate(seqs):
+        ref = vo.forward_tokens(cfg, w, t[None])["cls"][0]
+        one = e.forward_tokens(t[None].cuda(), vdr.OUT_CLS).float().cpu()[0]
+        r_ref = _rel_l2(got[i][None], ref[None])
+        r_one = _rel_l2(got[i][None], one[None])
+        assert r_ref <= gate_l2(layers) and r_one <= 4e-3, (i, lens[i], r_ref, r_one)
+    # padding content is irrelevant, bitwise
+    pad2 = pad.clone()
+    for i, t in enumerate(seqs):
+        pad2[i, t.shape[0]:] = -7.5
+    assert torch.equal(got, e.forward_tokens(pad2.cuda(), vdr.OUT_CLS, lengths=lens).float().cpu())
+    # lengths == S everywhere is the fixed-length path
+    full = e.forward_tokens(pad.cuda(), vdr.OUT_CLS, lengths=[S] * len(lens)).float().cpu()
+    assert _rel_l2(full, e.forward_tokens(pad.cuda(), vdr.OUT_CLS).float().cpu()) <= 4e-3
+    with pytest.raises(ValueError):
+        e.forward_tokens(pad.cuda(), vdr.OUT_CLS, lengths=[0] + lens[1:])
+
+
 @pytest.mark.parametrize("name", ["vit_hf_tiny", "vit_hf_p16"])
 def test_golden_transformers_crosscheck(golden_dir, name):
     import vdr

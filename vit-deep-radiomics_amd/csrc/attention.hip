@@ -29,6 +29,8 @@ struct AttnK {
   int qt_per_block;  // query tiles handled by one workgroup
   int n_chunks;      // key chunks of NT*32 keys
   int abl;           // diagnostic: 1 = no compute, 2 = no staging after the first item
+  const int* lens;   // non-null: per-batch-entry valid length = lens[b] + len_add (<= seq); keys past it are masked
+  int len_add;       //           (variable-length token sequences padded to seq)
   uint8_t* o_scale;  // non-null: `out` is an MX-fp8 payload [tokens][heads*64] and this its e8m0 scale array
   int64_t os_rows;   //           (mx.hip layout: [heads*2 blocks][os_rows], rows paired inside 64-row groups)
 };
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   const int hd = blockIdx.x - b * p.heads;
   const int HD = p.heads * 64;
   const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
+  const int len = p.lens ? min(p.seq, p.lens[b] + p.len_add) : p.seq;  // valid keys of this sequence
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
 
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     // mask keys >= seq (only tiles that straddle or lie beyond the end)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (kc0 + t * 32 + 32 > p.seq) {
+      if (kc0 + t * 32 + 32 > len) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int key = kc0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (key >= p.seq) s[t][e] = -INFINITY;
+          if (key >= len) s[t][e] = -INFINITY;
         }
       }
     }
@@ -527,7 +530,7 @@ static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
 }
 
 hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
-                            hipStream_t s, void* out_scale) {
+                            hipStream_t s, void* out_scale, const int* lens, int len_add) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return hipErrorInvalidValue;
   AttnK k;
   k.abl = variant / 10;
@@ -535,6 +538,8 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
   k.o_scale = (uint8_t*)out_scale;
+  k.lens = lens;
+  k.len_add = len_add;
   k.os_rows = mx_rows_pad((int64_t)batch * seq);
   k.seq = seq;
   k.heads = heads;
@@ -549,7 +554,7 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   }
   k.qt_per_block = nqt;
   k.n_chunks = 1;
-  if (variant == 2 || variant == 0) {
+  if ((variant == 2 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
     // persistent warp-specialised kernel (needs a few items per workgroup to pay off)
     if (seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7>(k, batch, s);  // nqt <= 7 compute waves
     if (variant == 2) {

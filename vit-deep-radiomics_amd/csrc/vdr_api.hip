@@ -549,7 +549,7 @@ int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, 
 }
 
 // L transformer blocks over x [M = mb*ntok rows]; leaves the result in w.x
-int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
+int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, const int* lens = nullptr, int len_add = 0) {
   const vdr_config& c = m->cfg;
   const int D = c.dim, F = c.mlp_hidden, H = c.heads;
   const int64_t M = (int64_t)mb * ntok;
@@ -604,7 +604,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
-        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, w.os), "attention");
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, w.os, lens, len_add), "attention");
       }
       if ((rc = gemm_mx(VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, D, D, D,
                         EPI_BIAS_RESID)))
@@ -642,7 +642,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
-        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
       {
@@ -669,7 +669,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok) {
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
       static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
-      VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s), "attention");
+      VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
     }
     if (c.pre_ln) {
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
@@ -1152,8 +1152,23 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
   return VDR_OK;
 }
 
+static int forward_tokens_impl(vdr_handle m, const void* tokens, int in_dtype, int batch, int seq, const int32_t* seq_lens,
+                               void* out, int out_mode, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 int vdr_forward_tokens(vdr_handle m, const void* tokens, int in_dtype, int batch, int seq, void* out, int out_mode,
                        int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_tokens_impl(m, tokens, in_dtype, batch, seq, nullptr, out, out_mode, out_dtype, workspace, workspace_bytes, stream);
+}
+
+int vdr_forward_tokens_varlen(vdr_handle m, const void* tokens, int in_dtype, int batch, int max_seq, const int32_t* seq_lens,
+                              void* out, int out_mode, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!seq_lens) return fail(m, VDR_ERR_INVALID, "seq_lens is null");
+  return forward_tokens_impl(m, tokens, in_dtype, batch, max_seq, seq_lens, out, out_mode, out_dtype, workspace, workspace_bytes,
+                             stream);
+}
+
+static int forward_tokens_impl(vdr_handle m, const void* tokens, int in_dtype, int batch, int seq, const int32_t* seq_lens,
+                               void* out, int out_mode, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
   if (!m || !tokens || !out || !workspace || batch <= 0 || seq <= 0) return fail(m, VDR_ERR_INVALID, "null/invalid argument");
   const vdr_config& c = m->cfg;
   if (c.patch) return fail(m, VDR_ERR_INVALID, "vdr_forward_tokens needs a token model (patch == 0)");
@@ -1193,7 +1208,7 @@ int vdr_forward_tokens(vdr_handle m, const void* tokens, int in_dtype, int batch
       Scope sc(m, s, VDR_K_ASSEMBLE, 0.0, (double)M * D * (in_es + 2));
       VDR_TRY(launch_assemble_tokens(tok, in_dtype == VDR_BF16, m->cls, nullptr, w.x, mb, seq, D, ncls, s), "assemble");
     }
-    if ((rc = run_blocks(m, s, w, mb, ntok))) return rc;
+    if ((rc = run_blocks(m, s, w, mb, ntok, seq_lens ? seq_lens + b0 : nullptr, ncls))) return rc;
     const int64_t rows_per = out_mode == VDR_OUT_CLS ? 1 : (out_mode == VDR_OUT_DENSE ? seq : ntok);
     char* o = (char*)out + (size_t)b0 * rows_per * out_row_bytes(m, out_dtype);
     if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;

@@ -76,7 +76,8 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 //   out_scale != NULL: `out` is written as MX-fp8 (payload [batch*seq][heads*64] bytes + e8m0 scales), the
 //   operand of the fp8 out-projection
 hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
-                            hipStream_t s, void* out_scale = nullptr);
+                            hipStream_t s, void* out_scale = nullptr, const int* lens = nullptr, int len_add = 0);
+//   lens != NULL: entry b attends over its first lens[b] + len_add rows only (sequences padded to seq)
 
 // SAM / MedSAM decomposed relative position bias (attention_relpos.hip)
 //   rel [tokens][heads][2S] fp32 = (q . Rh[qh - kh + S-1], q . Rw[qw - kw + S-1]); qkv rows are S*S-token

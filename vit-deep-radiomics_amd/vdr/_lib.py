@@ -44,6 +44,7 @@ SYMBOLS = {
     "vdr_workspace_bytes": (_I, [_P, _I, _I, C.POINTER(C.c_size_t)]),
     "vdr_forward": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, C.c_size_t, _P]),
     "vdr_forward_tokens": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P, C.c_size_t, _P]),
+    "vdr_forward_tokens_varlen": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P]),
     "vdr_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P]),
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_prepare_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),

@@ -146,7 +146,9 @@ class Engine:
                                      _DT[out.dtype], ws.data_ptr(), ws.numel(), _stream_ptr(self.device)), self.h)
         return out
 
-    def forward_tokens(self, tokens: torch.Tensor, out_mode: int = L.OUT_CLS, out_dtype=torch.float32) -> torch.Tensor:
+    def forward_tokens(self, tokens: torch.Tensor, out_mode: int = L.OUT_CLS, out_dtype=torch.float32,
+                       lengths=None) -> torch.Tensor:
+        """tokens [B,S,D]; lengths (optional, int [B]): sequence b is tokens[b, :lengths[b]], the rest padding."""
         cfg = self.cfg
         if tokens.dim() != 3 or tokens.shape[2] != cfg.dim:
             raise ValueError(f"tokens must be [B,S,{cfg.dim}], got {tuple(tokens.shape)}")
@@ -158,8 +160,17 @@ class Engine:
         shape = {L.OUT_CLS: (B, D), L.OUT_DENSE: (B, S, D), L.OUT_TOKENS: (B, S + c, D)}[out_mode]
         out = torch.empty(shape, dtype=out_dtype, device=self.device)
         ws = self._workspace(B, S)
-        L.check(self.lib.vdr_forward_tokens(self.h, tokens.data_ptr(), _DT[tokens.dtype], B, S, out.data_ptr(), out_mode,
-                                            _DT[out_dtype], ws.data_ptr(), ws.numel(), _stream_ptr(self.device)), self.h)
+        if lengths is None:
+            L.check(self.lib.vdr_forward_tokens(self.h, tokens.data_ptr(), _DT[tokens.dtype], B, S, out.data_ptr(), out_mode,
+                                                _DT[out_dtype], ws.data_ptr(), ws.numel(), _stream_ptr(self.device)), self.h)
+            return out
+        lens = torch.as_tensor(lengths, dtype=torch.int32)
+        if lens.shape != (B,) or int(lens.min()) < 1 or int(lens.max()) > S:
+            raise ValueError(f"lengths must be [B] with 1 <= length <= {S}")
+        lens = lens.to(self.device).contiguous()
+        L.check(self.lib.vdr_forward_tokens_varlen(self.h, tokens.data_ptr(), _DT[tokens.dtype], B, S, lens.data_ptr(),
+                                                   out.data_ptr(), out_mode, _DT[out_dtype], ws.data_ptr(), ws.numel(),
+                                                   _stream_ptr(self.device)), self.h)
         return out
 
     # ---- profiler ---------------------------------------------------------------------------------

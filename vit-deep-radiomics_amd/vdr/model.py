@@ -167,9 +167,15 @@ class TransformerNoduleClassifier:
     def to(self, *a, **k):
         return self
 
-    def __call__(self, x: torch.Tensor):
+    def __call__(self, x, lengths=None):
+        """x [B,S,D] -> (logits, cls) as the reference.  Variable-length batches (the reference runs batch_size 1
+        because its masked-voxel sequences differ in length): pass x padded to the longest sequence plus
+        `lengths` [B], or a list of [S_i, D] tensors (padded here)."""
         from . import ops
-        cls = self.engine.forward_tokens(x, L.OUT_CLS, torch.float32)
+        if isinstance(x, (list, tuple)):
+            lengths = [int(t.shape[0]) for t in x]
+            x = torch.nn.utils.rnn.pad_sequence([torch.as_tensor(t).float() for t in x], batch_first=True)
+        cls = self.engine.forward_tokens(x, L.OUT_CLS, torch.float32, lengths=lengths)
         hid = ops.linear(cls.to(torch.bfloat16), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
         logits = ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.num_classes].float()
         return logits, cls
