@@ -86,6 +86,25 @@ def test_linear_exact_integers_catches_layout_bugs(ops):
     assert torch.equal(y.float().cpu(), _bf(W).float().t())
 
 
+@pytest.mark.parametrize("variant", list(range(1, 25)))
+def test_linear_every_tile_variant_exact(ops, variant):
+    """Every tile configuration the library can be asked for (legacy single/double-stage kernels, the ring
+    kernels, ring2 = 32x32x16 MFMA, ring3 = 16x16x32 MFMA) on integer data: bit-exact, with bias, GELU-free
+    residual epilogue and ragged edges in M and N."""
+    from vdr import EPI_BIAS, EPI_BIAS_RESID
+    g = torch.Generator().manual_seed(variant)
+    for (M, N, K) in [(333, 776, 320), (64, 64, 64), (700, 1032, 128)]:
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-3, 4, (N,), generator=g).float()
+        r = torch.randint(-4, 5, (M, N), generator=g).float()
+        ref = x @ W.t() + b
+        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS, variant=variant)
+        assert torch.equal(y.float().cpu(), ref), f"variant {variant} bias {(M, N, K)}"
+        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=variant)
+        assert torch.equal(y.float().cpu(), ref + r), f"variant {variant} resid {(M, N, K)}"
+
+
 def test_linear_mixed_tile_heights_exact(ops):
     """Shapes with more than two tiles per CU make the default GEMM finish with a round of half-height
     tiles (gemm_ring2_kernel); integer data -> bit-exact against the fp32 reference, every row."""

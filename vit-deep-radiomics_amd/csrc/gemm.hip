@@ -462,6 +462,165 @@ VDR_DEV void gemm_ring2_body(const GemmK& p, const int64_t m0, const int n0, cha
 }
 
 
+// -------------------------------------------------------------------------------------------------
+// Ring variant 3: the ring2 pipeline on the 16x16x32 MFMA shape.  Same LDS image, same bytes read per unit
+// (8 ds_read_b128 per wave), same MFMA cycles (16 instructions of 4 passes instead of 8 of 8) -- but the chip
+// holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7): measured here, same box,
+// alternating processes, -5 ... -10 % on every GEMM of the forward.
+// A wave owns a 64 x 64 tile = 4 x 4 MFMA tiles; one MFMA consumes the unit's whole K = 32, so a step is split
+// by A row tiles instead of k-steps:
+//   top of step s :  B[0..3] (weight tiles) and Alo (activation row tiles 0, 1) of unit s are in registers
+//       read Ahi <- unit s                      | 8 MFMAs  B[jt] x Alo
+//       lgkmcnt(0); vmcnt: retire unit s+1; s_barrier; global_load_lds unit s+NST -> slot of unit s
+//       read Alo <- unit s+1                    | 8 MFMAs  B[jt] x Ahi, each B[jt] re-read from unit s+1 as
+//                                                 soon as its last MFMA of step s has been issued
+// -------------------------------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int NST, int EPI>
+VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, char* smem) {
+  constexpr int TM = 2, TN = 2;  // in units of 32: the wave tile is 64 x 64
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * 64;
+  constexpr int BN = WAVES_N * 64;
+  constexpr int UNIT = (BM + BN) * 64;
+  constexpr int NA = BM / 16 / NW;
+  constexpr int NB = BN / 16 / NW;
+  constexpr int G = NA + NB;
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
+  static_assert((NST - 1) * G <= 63, "vmcnt range");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int srow = lane >> 2;
+  const int spc = lane & 3;
+  const bf16_t* a_src[NA];
+  const bf16_t* b_src[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int r = (wave * NA + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int64_t gr = m0 + r;
+    gr = gr < p.M ? gr : p.M - 1;
+    const int64_t aoff = p.a_rpg > 0 ? (gr / p.a_rpg) * p.a_gs + (gr % p.a_rpg) * p.a_is : gr * p.lda;
+    a_src[q] = p.A + aoff + c * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int r = (wave * NB + q) * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int gr = n0 + r;
+    gr = gr < p.N ? gr : p.N - 1;
+    b_src[q] = p.W + (int64_t)gr * p.ldw + c * 8;
+  }
+
+  // fragment of MFMA tile t (16 rows): lane (r = lane & 15, q = lane >> 4) reads the 16-B chunk q of row r; the
+  // chunk swizzle (row >> 2) & 3 of the LDS image equals (lane >> 2) & 3 because tile bases are multiples of 16
+  const int r15 = lane & 15;
+  const int chq = ((lane >> 4) ^ ((lane >> 2) & 3)) * 16;
+  const int a_base = (wm * 64 + r15) * 64 + chq;
+  const int b_base = BM * 64 + (wn * 64 + r15) * 64 + chq;
+
+  Acc16 acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.t[j][i][e] = 0.0f;
+
+  const int nsteps = p.K >> 5;
+  const bool do_epi = __builtin_amdgcn_readfirstlane(p.abl & 1) == 0;
+  auto stage = [&](int slot) {
+    char* d = smem + slot * UNIT;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      glds16(a_src[q], d + (wave * NA + q) * 1024);
+      a_src[q] += 32;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      glds16(b_src[q], d + BM * 64 + (wave * NB + q) * 1024);
+      b_src[q] += 32;
+    }
+  };
+  auto ld = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(smem + slot * UNIT + off); };
+  auto retire = [&](int u, int issued_upto) {
+    const int younger = issued_upto - u;
+    if (younger >= NST - 1) {
+      wait_vmcnt<(NST - 1) * G>();
+    } else if (younger == NST - 2 && NST >= 3) {
+      wait_vmcnt<(NST - 2) * G>();
+    } else if (younger == 1 && NST >= 4) {
+      wait_vmcnt<G>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  };
+  bf16x8 fb[4], alo[2], ahi[2];
+
+  int issued = -1;
+#pragma unroll
+  for (int u = 0; u < NST; ++u)
+    if (u < nsteps) {
+      stage(u);
+      issued = u;
+    }
+  retire(0, issued);
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = ld(0, b_base + j * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) alo[i] = ld(0, a_base + i * 1024);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const int nslot = slot + 1 == NST ? 0 : slot + 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc.t[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], alo[i], acc.t[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ahi[i] = ld(slot, a_base + (2 + i) * 1024);  // lands under the MFMAs just issued
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave holds every fragment of unit s it still needs
+    if (s + 1 < nsteps) {
+      retire(s + 1, issued);
+      __builtin_amdgcn_s_barrier();
+      if (s + NST < nsteps) {
+        stage(slot);
+        issued = s + NST;
+      }
+    }
+    // unit s+1 (after the last unit these reads fetch stale, unused bytes: an unconditional read costs nothing,
+    // a conditional one a second register set)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) alo[i] = ld(nslot, a_base + i * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc.t[j][2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], ahi[i], acc.t[j][2 + i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fb[j] = ld(nslot, b_base + j * 1024);  // B[j] of unit s is dead: fetch unit s+1's under the remaining MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = nslot;
+  }
+
+  if (!do_epi && acc.t[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
+  __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
+  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+template <int WAVES_M, int WAVES_N, int NST, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring3_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wg = xcd_remap(blockIdx.x, p.nwg);
+  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  gemm_ring3_body<WAVES_M, WAVES_N, NST, EPI>(p, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
+}
+
 // Workgroups [0, p.nwg_big) compute BM x BN tiles of rows [0, p.m_split); the remaining workgroups
 // compute (BM/2) x BN tiles of rows [p.m_split, M).  The hardware dispatches workgroups in index
 // order, so the half-height tiles form the last, partial round: a tile count that leaves the final
@@ -584,7 +743,9 @@ int g_gemm_split = 0;  // VDR_GEMM_SPLIT=1 enables the mixed-height last round (
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int E>
 static auto launch_pick() -> void (*)(GemmK) {
-  if constexpr (PIPE >= 20)
+  if constexpr (PIPE >= 30)
+    return gemm_ring3_kernel<WAVES_M, WAVES_N, PIPE - 30, E>;
+  else if constexpr (PIPE >= 20)
     return gemm_ring2_kernel<WAVES_M, WAVES_N, TM, TN, PIPE - 20, E>;
   else if constexpr (PIPE >= 10)
     return gemm_ring_kernel<WAVES_M, WAVES_N, TM, TN, PIPE - 10, E>;
@@ -628,7 +789,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.nwg = (int)nwg;
   k.nwg_big = (int)nwg;
   k.m_split = a.M;
-  if (PIPE >= 20 && WAVES_M == 2 && (TN % 4) == 0 && g_gemm_split != 0) {
+  if (PIPE >= 20 && PIPE < 30 && WAVES_M == 2 && (TN % 4) == 0 && g_gemm_split != 0) {
     // mixed tile heights: finish with one round of half-height tiles when that is shorter than a
     // partial round of full ones
     static int n_cu = 0;
@@ -679,8 +840,9 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   }
 
   const dim3 grid((unsigned)k.nwg), block(WAVES_M * WAVES_N * 64);
-  const size_t lds_ring2 = (size_t)(BM + BN) * 64 * (PIPE - 20) > (size_t)WAVES_M * WAVES_N * 32 * 272
-                               ? (size_t)(BM + BN) * 64 * (PIPE - 20)
+  constexpr int RING_SLOTS = PIPE >= 30 ? PIPE - 30 : PIPE - 20;
+  const size_t lds_ring2 = (size_t)(BM + BN) * 64 * RING_SLOTS > (size_t)WAVES_M * WAVES_N * 32 * 272
+                               ? (size_t)(BM + BN) * 64 * RING_SLOTS
                                : (size_t)WAVES_M * WAVES_N * 32 * 272;
   const size_t lds = PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
@@ -707,7 +869,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   return hipGetLastError();
 }
 
-int gemm_num_variants() { return 22; }
+int gemm_num_variants() { return 25; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
@@ -761,6 +923,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
       return launch_cfg<4, 2, 2, 2, 23>(a, epilogue, s);  // ring2: 256x128, 8 waves (wave 64x64), 3 x 24 KB, 2 WG/CU
     case 21:
       return launch_cfg<4, 4, 2, 2, 23>(a, epilogue, s);  // ring2: 256x256, 16 waves (wave 64x64), 3 x 32 KB
+    case 22:
+      return launch_cfg<2, 4, 2, 2, 33>(a, epilogue, s);  // ring3 (16x16x32 MFMA): 128x256, 8 waves, 3 x 24 KB, 2 WG/CU
+    case 23:
+      return launch_cfg<4, 4, 2, 2, 33>(a, epilogue, s);  // ring3: 256x256, 16 waves, 3 x 32 KB
+    case 24:
+      return launch_cfg<2, 2, 2, 2, 33>(a, epilogue, s);  // ring3: 128x128, 4 waves, 3 x 16 KB, 3 WG/CU
     default:
       return hipErrorInvalidValue;
   }

@@ -284,14 +284,44 @@ VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc
 // staging image (row stride 272 B: conflict-free ds_write_b128 / ds_read_b128) and come back with
 // 16 lanes per output row, so every global access of the epilogue (bias, residual, store) touches
 // whole 128-B lines instead of 32 rows x 16 B per instruction.
-template <int EPI, int TM, int TN>
-VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int64_t m_base, int n_base, int lane) {
+// staging of one 32 (m) x 64 (n) block (row block i, column-pair block jp) of a wave's accumulators as fp32
+// [32][64] with row stride 272 B, for the two accumulator layouts:
+//   32x32x16 MFMA: acc[j][i][4g + e] = D[n = 32j + 8g + 4h + e][m = 32i + (lane & 31)]
+template <int TM, int TN>
+VDR_DEV void stage_acc_block(const f32x16 (&acc)[TN][TM], char* stg, int i, int jp, int lane) {
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = acc[2 * jp + jj][i][4 * g + e];
+      *reinterpret_cast<f32x4*>(stg + l31 * 272 + (jj * 32 + 8 * g + 4 * h) * 4) = t;
+    }
+}
+//   16x16x32 MFMA (64 x 64 wave tile = 4 x 4 tiles): t[jt][it][e] = D[n = 16jt + 4(lane >> 4) + e][m = 16it + (lane & 15)]
+struct Acc16 {
+  f32x4 t[4][4];
+};
+template <int TM, int TN>
+VDR_DEV void stage_acc_block(const Acc16& acc, char* stg, int i, int jp, int lane) {
+  static_assert(TM == 2 && TN == 2, "Acc16 is a 64 x 64 wave tile");
+  (void)jp;
+#pragma unroll
+  for (int it2 = 0; it2 < 2; ++it2)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+      *reinterpret_cast<f32x4*>(stg + (it2 * 16 + (lane & 15)) * 272 + (jt * 16 + 4 * (lane >> 4)) * 4) = acc.t[jt][2 * i + it2];
+}
+
+template <int EPI, int TM, int TN, typename AccT>
+VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane) {
   constexpr int E = epi_base(EPI);
   constexpr bool MXO = epi_mx_out(EPI);
   (void)MXO;
   constexpr int RS = 272;
   static_assert(TN % 2 == 0, "column tiles are staged in pairs");
-  const int h = lane >> 5, l31 = lane & 31;
   // LayerNorm fold: (mean, rstd) of the 4*TM rows this lane owns in the read-back phase, fetched up front
   float st_mu[TM][4], st_rs[TM][4];
 #pragma unroll
@@ -312,15 +342,7 @@ VDR_DEV void epilogue_lds(const GemmK& p, f32x16 (&acc)[TN][TM], char* stg, int6
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int jp = 0; jp < TN / 2; ++jp) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 t;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = acc[2 * jp + jj][i][4 * g + e];
-          *reinterpret_cast<f32x4*>(stg + l31 * RS + (jj * 32 + 8 * g + 4 * h) * 4) = t;
-        }
+      stage_acc_block<TM, TN>(acc, stg, i, jp, lane);
       if (E != EPI_SWIGLU) {
         // 8 lanes per row (8 columns each), 8 rows per instruction: whole 128-B lines, 16-B accesses
 #pragma unroll

@@ -481,14 +481,25 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   if (forced >= 0) return forced;
   // small problems (a single 1024^2 SAM slice is M = 4096): fewer 128x256 tiles than CUs -> 128x128 tiles
   // (measured, MedSAM batch 1: fc2 0.72 -> 0.57 ms, proj 0.35 -> 0.31 ms per forward)
-  if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) return 16;
+  if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) {
+    static const int small = env_int("VDR_GEMM_VARIANT_SMALL", 24);
+    return small;  // ring3 128x128, 4 waves, 3 workgroups per CU
+  }
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
+  // per-class override for tuning: VDR_GEMM_VARIANT_QKV / _PROJ / _FC1 / _FC2
+  static const int o_qkv = env_int("VDR_GEMM_VARIANT_QKV", -1), o_proj = env_int("VDR_GEMM_VARIANT_PROJ", -1),
+                   o_fc1 = env_int("VDR_GEMM_VARIANT_FC1", -1), o_fc2 = env_int("VDR_GEMM_VARIANT_FC2", -1);
+  const int o = cls == VDR_K_GEMM_QKV ? o_qkv : cls == VDR_K_GEMM_PROJ ? o_proj : cls == VDR_K_GEMM_FC1 ? o_fc1
+                : cls == VDR_K_GEMM_FC2 ? o_fc2 : -1;
+  if (o >= 0) return o;
+  // ring3 = the ring2 pipeline on the 16x16x32 MFMA shape (the chip holds a higher clock on it): measured in the
+  // full forward, same box: qkv 2.64 -> 2.40 ms, fc1 3.96 -> 3.74, fc2 3.48 -> 3.36, proj 1.39 -> 1.37 per step
   switch (cls) {
     case VDR_K_GEMM_QKV:
-      return 21;  // ring2 256x256, 16 waves, 3 x 32 KB ring
+      return 23;  // ring3 256x256, 16 waves, 3 x 32 KB ring
     default:
-      return 19;  // ring2 128x256, 8 waves, 3 x 24 KB ring, 2 workgroups per CU
+      return 22;  // ring3 128x256, 8 waves, 3 x 24 KB ring, 2 workgroups per CU
   }
 }
 
@@ -1268,6 +1279,8 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
   g.ldc = epilogue == VDR_EPI_SWIGLU ? N / 2 : N;
   g.ldr = g.ldc;
   g.omap = identity_map();
+  if (variant == 0)  // library default: what the forward itself would pick for this shape
+    variant = gemm_variant_for(N >= 2304 ? VDR_K_GEMM_QKV : VDR_K_GEMM_FC1, M, N);
   OP_TRY(launch_gemm(g, epilogue, variant, (hipStream_t)stream), "gemm");
   return VDR_OK;
 }
