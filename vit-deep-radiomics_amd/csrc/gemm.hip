@@ -617,7 +617,8 @@ template <int WAVES_M, int WAVES_N, int NST, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring3_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wg = xcd_remap(blockIdx.x, p.nwg);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  int tm, tn;
+  tile_of(p, wg, tm, tn);
   gemm_ring3_body<WAVES_M, WAVES_N, NST, EPI>(p, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
 }
 
@@ -776,6 +777,17 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.off = a.omap.off;
   const int64_t tiles_m = (a.M + BM - 1) / BM;
   k.tiles_n = (a.N + BN - 1) / BN;
+  k.tiles_m = (int)tiles_m;
+  {
+    // column-group width (ring3 kernels): as many W panels (BN x K bf16) as fit in half of an XCD's 4 MB L2, and only
+    // when W as a whole exceeds that L2 (ViT-B: fc1 4.7 MB yes, qkv 3.5 MB no -- measured: fc1 HBM-side reads 790 ->
+    // 446 MB and -2.6 % time, qkv +3 % time).  VDR_GEMM_GN overrides (0 = row-major).
+    static const int gn_env = [] { const char* e = getenv("VDR_GEMM_GN"); return e && *e ? atoi(e) : -1; }();
+    const size_t panel = (size_t)BN * a.K * 2, whole = (size_t)a.N * a.K * 2;
+    int gn = whole > (4u << 20) ? (int)((2u << 20) / panel) : 0;
+    if (gn < 2) gn = 0;  // a single column at a time re-reads A once per column: never better than row-major
+    k.gn = gn_env >= 0 ? gn_env : gn;
+  }
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
   {

@@ -22,6 +22,7 @@ struct GemmK {
   int64_t gstride;
   int off;
   int tiles_n;
+  int tiles_m = 0, gn = 0;  // gn > 0: tiles are walked in column groups of gn tile columns (see tile_of)
   int nwg;
   int nwg_big;      // ring2: workgroups [0, nwg_big) use the full tile height, the rest half of it
   int64_t m_split;  // ring2: first row covered by half-height tiles
@@ -405,6 +406,24 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
       }
     }
   }
+}
+
+// logical tile id -> (tile row, tile column).  gn == 0: row-major (the column tiles of a tile row are neighbours and
+// share the A panel; right when the whole W fits the XCD's L2 or K is long).  gn > 0: column groups of gn tile
+// columns are swept over all tile rows before the next group starts: the gn W panels of a group stay resident in
+// the 4 MB L2 of the XCD while A streams through once per group instead of once per L2 eviction.
+VDR_DEV void tile_of(const GemmK& p, int wg, int& tm, int& tn) {
+  if (p.gn <= 0 || p.gn >= p.tiles_n) {
+    tm = wg / p.tiles_n;
+    tn = wg - tm * p.tiles_n;
+    return;
+  }
+  const int per_group = p.tiles_m * p.gn;
+  const int g = wg / per_group;
+  const int r = wg - g * per_group;
+  const int width = min(p.gn, p.tiles_n - g * p.gn);  // the last group may be narrower
+  tm = r / width;
+  tn = g * p.gn + (r - tm * width);
 }
 
 template <int N>
