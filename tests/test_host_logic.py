@@ -108,3 +108,27 @@ def test_pipeline_roi_host_logic_matches_reference_goldens(golden_dir):
         assert np.array_equal(pipeline.crop_image(f, *[int(v) for v in r[f"c{i}_crop_args"]]), r[f"c{i}_crop"])
     with __import__("pytest").raises(ValueError):
         pipeline.extract_coords(np.zeros((4, 4), dtype=bool), 1)
+
+
+def test_feature_metadata_table_layout(tmp_path):
+    """The per-patient parquet the reference writes next to the HDF5 features (tfds_dense_descriptor.py:452-491):
+    column names / order, feature_id numbering across augmentations, the 3 x 4 augmentation loop order, and a
+    parquet round trip (pandas + pyarrow are in the image)."""
+    import numpy as np
+    import pandas as pd
+    from vdr import pipeline
+
+    res = np.array([0.8, 0.8, 0.8])
+    df = pipeline.feature_metadata(5, "LUNG-001", 1, "santa_maria_dataset", "ct", res)
+    assert list(df.columns) == ["feature_id", "slice", "angle", "flip", "patient_id", "label", "dataset", "modality",
+                                "augmentation", "spatial_res"]
+    assert len(df) == 5 * 12 and list(df["feature_id"]) == list(range(60))
+    assert list(df["slice"][:7]) == [0, 1, 2, 3, 4, 0, 1]
+    assert list(df["angle"][::5]) == [0, 45, 90, 135] * 3
+    assert [f for f in df["flip"][::20]] == [None, "horizontal", "vertical"]
+    assert set(df["dataset"]) == {"santa_maria"} and bool(df["augmentation"].all())
+    path = tmp_path / "LUNG-001_ct.parquet"
+    pipeline.save_metadata(df, str(path))
+    back = pd.read_parquet(path)
+    assert list(back.columns) == list(df.columns) and len(back) == 60
+    assert np.allclose(np.asarray(back["spatial_res"][0], dtype=float), res)

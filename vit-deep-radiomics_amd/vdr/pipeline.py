@@ -131,3 +131,42 @@ def save_features(filename, all_features, all_masks, patient_id):
         for i, (feature, mask) in enumerate(zip(all_features, all_masks)):
             grp.create_dataset(f"features/{i}", compression="lzf", data=feature, chunks=feature.shape)
             grp.create_dataset(f"masks/{i}", compression="lzf", data=mask, chunks=mask.shape)
+
+
+# ---- tfds_dense_descriptor.py:452-491 ------------------------------------------------------------------------
+AUGMENTATIONS = [(flip, angle) for flip in (None, "horizontal", "vertical") for angle in range(0, 180, 45)]
+
+
+def feature_metadata(n_features_per_aug, patient_id, label, dataset_name, modality, spatial_res, augmentations=None):
+    """The per-patient table the reference stores next to the HDF5 features (`{patient}_{modality}.parquet`):
+    one row per feature map, columns feature_id, slice, angle, flip, patient_id, label, dataset, modality,
+    augmentation, spatial_res — what train_models.py:147-157 / prepare_df read.
+
+    n_features_per_aug: number of slices produced for each (flip, angle) in `augmentations` (default: the
+    reference's 3 flips x 4 angles, in its loop order).  `augmentation` is True on every row: the reference
+    computes `not (df['flip'] is None and angle == 0)` with `df['flip'] is None` evaluated on the Series object
+    (always False), and consumers were written against that output."""
+    import pandas as pd
+
+    augmentations = AUGMENTATIONS if augmentations is None else list(augmentations)
+    if isinstance(n_features_per_aug, int):
+        n_features_per_aug = [n_features_per_aug] * len(augmentations)
+    rows = {"slice": [], "angle": [], "flip": []}
+    for (flip, angle), n in zip(augmentations, n_features_per_aug):
+        rows["angle"] += [angle] * n
+        rows["flip"] += [flip] * n
+        rows["slice"] += list(range(n))
+    df = pd.DataFrame(rows)
+    df.reset_index(drop=False, inplace=True)
+    df = df.rename(columns={"index": "feature_id"})
+    df["patient_id"] = patient_id
+    df["label"] = label
+    df["dataset"] = dataset_name.replace("_dataset", "")
+    df["modality"] = modality
+    df["augmentation"] = True
+    df["spatial_res"] = [spatial_res] * df.shape[0]
+    return df
+
+
+def save_metadata(df, df_path):
+    df.to_parquet(df_path)
