@@ -346,7 +346,7 @@ int resolve(vdr_model* m) {
 struct Carve {
   char *x, *h, *qkv, *o, *u;
   char* hg = nullptr;    // SAM: LN1 output of the global blocks (h holds the windowed, zero-padded order)
-  float* rel = nullptr;  // SAM: relative position terms [tokens][heads][2S]
+  float* rel = nullptr;  // SAM: rel-pos products T[tokens][heads][relpos_npad(S)] (q . every table row)
   char *hs = nullptr, *us = nullptr, *os = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h, u, o
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;

@@ -80,8 +80,7 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
 //   lens != NULL: entry b attends over its first lens[b] + len_add rows only (sequences padded to seq)
 
 // SAM / MedSAM decomposed relative position bias (attention_relpos.hip)
-//   rel [tokens][heads][2S] fp32 = (q . Rh[qh - kh + S-1], q . Rw[qw - kw + S-1]); qkv rows are S*S-token
-//   windows (or whole grids) back to back
+//   qkv rows are S*S-token windows (or whole grids) back to back
 //   table [Npad][64] bf16: rows [0, 2S-1) = rel_pos_h, rows [Npad/2, Npad/2 + 2S-1) = rel_pos_w, rest zero;
 //   Npad = relpos_npad(S).  T = q . table^T is one GEMM over (token, head) rows (launch_gemm with a_rpg).
 // ---- MX-fp8 (mx.hip, gemm_mx.hip) ---------------------------------------------------------------------
