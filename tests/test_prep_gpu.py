@@ -117,3 +117,31 @@ def test_generate_features_batched_pipeline_vs_oracle():
         rel = np.linalg.norm(feats[i] - want) / np.linalg.norm(want)
         assert rel < 2e-2, (i, rel)
         assert np.array_equal(masks[i], po.extract_roi(mask_c[:, :, i] > 0, big_c))
+
+
+def test_extract_patient_features_augmentation_loop():
+    """The per-patient loop (tfds_dense_descriptor.py:452-491) on a small SAM geometry: 3 flips x 2 angles, list
+    lengths, metadata rows in loop order, and the flipped pass equal to running the flipped volume explicitly."""
+    import vdr
+    from vdr import pipeline
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64)
+    w = so.make_weights(cfg, seed=22)
+    vc = vdr.VdrConfig(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, has_cls=False, window=7,
+                       global_blocks=(1,), neck_chans=64)
+    model = vdr.VitDescriptorModel(vc, w, "medsam", torch.device("cuda"))
+    model.model_name = "medsam"
+    rng = np.random.default_rng(9)
+    H, W, S = 64, 60, 4
+    img = rng.random((H, W, S)).astype(np.float32)
+    mask = np.zeros((H, W, S), dtype=bool)
+    mask[20:33, 25:41, 1:3] = True
+    feats, masks, df = pipeline.extract_patient_features(model, img, mask, "P1", 0, "stanford_dataset", "pet",
+                                                         np.array([0.8, 0.8, 0.8]), angles=(0, 90))
+    assert len(feats) == len(masks) == len(df) == 3 * 2 * S
+    assert list(df["flip"][::2 * S]) == [None, "horizontal", "vertical"] and list(df["angle"][::S][:2]) == [0, 90]
+    assert list(df["feature_id"]) == list(range(len(df))) and set(df["dataset"]) == {"stanford"}
+    # horizontal flip, angle 0 == generate_features on the explicitly flipped volume
+    f2, m2 = pipeline.generate_features(model, np.ascontiguousarray(img[:, ::-1]), np.ascontiguousarray(mask[:, ::-1]))
+    for i in range(S):
+        assert np.array_equal(feats[2 * S + i], f2[i]) and np.array_equal(masks[2 * S + i], m2[i])

@@ -168,5 +168,43 @@ def feature_metadata(n_features_per_aug, patient_id, label, dataset_name, modali
     return df
 
 
+def rotate_image(image, mask, angle, axes=(0, 1)):
+    """tfds_dense_descriptor.py:327-350 verbatim in behaviour, on the CPU with scipy (cubic-spline rotation is the
+    one pre-processing step that has no GPU kernel here: DESIGN.md §6): image clipped to [0, 1], mask > 0."""
+    image, mask = np.asarray(image), np.asarray(mask)
+    if angle == 0:
+        return image.copy(), mask.copy()
+    from scipy.ndimage import rotate
+    image_rot = np.clip(rotate(image, angle, axes=axes, reshape=False, mode="nearest"), 0, 1)
+    mask_rot = rotate(mask, angle, axes=axes, reshape=False, mode="nearest") > 0
+    return image_rot, mask_rot
+
+
+def extract_patient_features(model, img_raw, mask_raw, patient_id, label, dataset_name, modality, spatial_res,
+                             flips=(None, "horizontal", "vertical"), angles=(0, 45, 90, 135), max_batch=16):
+    """The reference's per-patient augmentation loop (tfds_dense_descriptor.py:452-491): for every flip x angle,
+    generate_features over the whole volume; returns (all_features, all_masks, metadata DataFrame) ready for
+    save_features / save_metadata.  Flips are host-side views copied once per augmentation, rotations by a non-zero
+    angle go through rotate_image (scipy, CPU) exactly as the reference does; everything after that (resize, encoder,
+    ROI crop) runs batched on the GPU."""
+    all_features, all_masks, counts, augs = [], [], [], []
+    img_np, mask_np = np.asarray(img_raw), np.asarray(mask_raw)
+
+    def flipped(a, flip_type):  # flip_image (:305-324)
+        return a[:, ::-1] if flip_type == "horizontal" else a[::-1] if flip_type == "vertical" else a
+
+    for flip_type in flips:
+        im_f, m_f = flipped(img_np, flip_type), flipped(mask_np, flip_type)
+        for angle in angles:
+            im, m = rotate_image(im_f, m_f, angle)
+            feats, fmasks = generate_features(model, np.ascontiguousarray(im), np.ascontiguousarray(m), max_batch=max_batch)
+            all_features += feats
+            all_masks += fmasks
+            counts.append(len(feats))
+            augs.append((flip_type, angle))
+    df = feature_metadata(counts, patient_id, label, dataset_name, modality, spatial_res, augmentations=augs)
+    return all_features, all_masks, df
+
+
 def save_metadata(df, df_path):
     df.to_parquet(df_path)
