@@ -65,8 +65,37 @@ def run(dtype, batch=256, steps=10, warmup=3):
             "out": list(y.shape)}
 
 
+@torch.no_grad()
+def run_sam(dtype, batch=1, steps=10, warmup=3):
+    """The reference's default backbone is the SAM ViT-B image encoder run eagerly in fp32, one slice per call
+    (tfds_dense_descriptor.py:123).  segment_anything is not installed here; transformers' SamVisionModel is the
+    same architecture (random init, no download)."""
+    from transformers import SamVisionConfig, SamVisionModel
+    torch.manual_seed(0)
+    m = SamVisionModel(SamVisionConfig()).cuda().to(dtype).eval()
+    x = torch.rand(batch, 3, 1024, 1024, device="cuda", dtype=dtype)
+    for _ in range(warmup):
+        m(pixel_values=x)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(steps):
+        y = m(pixel_values=x).last_hidden_state
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / steps
+    return {"dtype": str(dtype).replace("torch.", ""), "batch": batch, "ms_per_step": round(ms, 3),
+            "slices_per_s": round(batch / ms * 1e3, 1), "out": list(y.shape)}
+
+
 if __name__ == "__main__":
     if not torch.cuda.is_available():
         sys.exit("needs a GPU")
     for dt in (torch.float32, torch.bfloat16):
         print(json.dumps({"what": "PyTorch-ROCm eager ViT-B/16 224^2 batch 256 CLS", **run(dt)}), flush=True)
+    for dt, b in ((torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 4)):
+        try:
+            print(json.dumps({"what": "PyTorch-ROCm eager SAM ViT-B 1024^2 image encoder (transformers SamVisionModel)",
+                              **run_sam(dt, b)}), flush=True)
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"what": "SAM baseline failed", "error": repr(e)[:200]}), flush=True)
