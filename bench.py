@@ -95,8 +95,9 @@ def main():
     ap.add_argument("--model", type=str, default="vit_base16_224")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
-    ap.add_argument("--fp8", action="store_true",
-                    help="qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline dtype)")
+    ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0,
+                    help="1: qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline "
+                         "dtype); 2: the out-projection too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
@@ -227,7 +228,7 @@ def main():
                      else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} CLS-feature extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "fp8 (MX e4m3 qkv/fc1/fc2, bf16 elsewhere)" if a.fp8 else "bf16", "data": "synthetic",
+               "dtype": ("fp8 (MX e4m3 qkv/fc1/fc2" + ("/proj" if a.fp8 >= 2 else "") + ", bf16 elsewhere)") if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
                                        f"[{total},64,64,256] fp32" if sam else
                                        f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32")

@@ -99,7 +99,7 @@ typedef struct {
   int32_t global_mask;/* bit i set: block i attends over the whole grid (SAM ViT-B: 2,5,8,11 = 0x924)  */
   int32_t neck_chans; /* output channels of the conv neck (256); 1x1 conv, LN2d, 3x3 conv, LN2d        */
   /* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"): */
-  int32_t fp8;        /* 1: qkv / proj / fc1 (w12) / fc2 (w3) weights are kept as MX-fp8 (OCP e4m3 + e8m0 scale per 32 K      */
+  int32_t fp8;        /* 1: qkv / fc1 (w12) / fc2 (w3) — 2: also the out-projection — weights are kept as MX-fp8 (OCP e4m3 + e8m0 scale per 32 K      */
                       /* elements) and run on v_mfma_scale_f32_32x32x64_f8f6f4 with MX-fp8 activations; pre_ln only    */
 } vdr_config;
 

@@ -36,7 +36,7 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=False):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
@@ -188,11 +188,12 @@ def test_fp8_small_vit_all_outputs(name):
     w = vo.make_weights(cfg, seed=3, scale=0.05)
     x = vo.make_images(cfg, 5, seed=4)
     ref = vo.forward_images(cfg, w, x)
-    emx = vo.forward_images(cfg, w, x, emulate_bf16="mx")
-    e = _engine(cfg, w, fp8=True)
     xd = x.cuda()
-    _gate_fp8(e.forward(xd, vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{name} fp8 cls")
-    _gate_fp8(e.forward(xd, vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{name} fp8 dense")
+    for level, mode in ((1, "mx"), (2, "mx2")):
+        emx = vo.forward_images(cfg, w, x, emulate_bf16=mode)
+        e = _engine(cfg, w, fp8=level)
+        _gate_fp8(e.forward(xd, vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{name} fp8={level} cls")
+        _gate_fp8(e.forward(xd, vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{name} fp8={level} dense")
     # the fp8 path is still batch-independent and deterministic
     a = e.forward(xd, vdr.OUT_CLS)
     b = e.forward(xd[[3, 1, 4, 0, 2]], vdr.OUT_CLS)
@@ -209,10 +210,11 @@ def test_fp8_dinov2_giant14_config5_geometry():
         w = vo.make_weights(cfg, seed=6)
         x = vo.make_images(cfg, 3, seed=7)
         ref = vo.forward_images(cfg, w, x)
-        emx = vo.forward_images(cfg, w, x, emulate_bf16="mx")
-        e = _engine(cfg, w, fp8=True)
-        _gate_fp8(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{tag} fp8 cls")
-        _gate_fp8(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{tag} fp8 dense")
+        for level, mode in ((1, "mx"), (2, "mx2")):
+            emx = vo.forward_images(cfg, w, x, emulate_bf16=mode)
+            e = _engine(cfg, w, fp8=level)
+            _gate_fp8(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{tag} fp8={level} cls")
+            _gate_fp8(e.forward(x.cuda(), vdr.OUT_DENSE), ref["dense"], emx["dense"], cfg.layers, f"{tag} fp8={level} dense")
 
 
 def test_fp8_is_refused_where_it_is_not_implemented():

@@ -571,6 +571,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
     // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
     // operands); the residual stream and the attention arithmetic stay bf16 / fp32.
     const int N1 = sw ? 2 * F : F;
+    const bool proj_mx = c.fp8 >= 2;  // fp8 = 1: qkv / fc1 / fc2; fp8 = 2: the out-projection (and the attention output) too
     auto mx_variant = [&](int cls, int N) {
       static const int forced = env_int("VDR_MX_VARIANT", -1);
       if (forced >= 0) return forced;
@@ -615,11 +616,15 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
-        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, w.os, lens, len_add), "attention");
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, proj_mx ? w.os : nullptr, lens, len_add), "attention");
       }
-      if ((rc = gemm_mx(VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, D, D, D,
-                        EPI_BIAS_RESID)))
+      if (proj_mx) {
+        if ((rc = gemm_mx(VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, D, D, D,
+                          EPI_BIAS_RESID)))
+          return rc;
+      } else if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) {
         return rc;
+      }
       {
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");

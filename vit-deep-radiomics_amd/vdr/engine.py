@@ -33,7 +33,7 @@ class VdrConfig:
     window: int = 0            # SAM: windowed attention side (14) + decomposed rel-pos
     global_blocks: tuple = ()  # SAM: blocks with global attention (2, 5, 8, 11)
     neck_chans: int = 0        # SAM: conv neck output channels (256)
-    fp8: bool = False          # qkv / fc1 / fc2 weights and their activations as MX-fp8 (BASELINE config 5)
+    fp8: int = 0               # 1: qkv / fc1 / fc2 as MX-fp8 (BASELINE config 5); 2: the out-projection too
 
     @property
     def n_patches(self):

@@ -89,7 +89,7 @@ class VitDescriptorModel:
 
 
 def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0,
-               fp8: bool = False):
+               fp8: int = 0):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
     torch.load(weights_only=True).  weights: the same dict passed directly.
@@ -98,7 +98,7 @@ def load_model(model_name: str, model_path=None, weights=None, device=None, micr
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
     cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams,
-                       "fp8": bool(fp8) or ARCHS[model_name].fp8})
+                       "fp8": int(fp8) or int(ARCHS[model_name].fp8)})
     if weights is None:
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
