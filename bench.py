@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0,
                     help="1: qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline "
                          "dtype); 2: the out-projection too")
+    ap.add_argument("--out", choices=["cls", "dense"], default="cls",
+                    help="cls: [N, D] CLS features (headline); dense: [N, n*D] per-patch descriptors (BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
@@ -137,15 +139,18 @@ def main():
     images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g)  # synthetic [0,1)
     images = (images if sam else images.to(torch.bfloat16)).to(dev)  # the reference feeds MedSAM fp32 slices
     total = B * world
+    dense = a.out == "dense" and not sam
     if sam:  # dense descriptor maps [N, 64, 64, 256] fp32, flattened to rows for the gather
         D = ocfg.grid * ocfg.grid * ocfg.out_chans
+    elif dense:  # per-patch token descriptors [N, n, D] fp32, one row per image for the gather
+        D = (ocfg.img // ocfg.patch) ** 2 * ocfg.dim
     feats = torch.empty((total, D), dtype=torch.float32, device=dev)  # final row-ordered [N, D] matrix
     # single GPU: the forward writes the matrix directly; multi GPU: each rank's rows go to a send buffer
     # and ONE all-gather lays them out in rank (= dataset) order
     mine = feats if world == 1 else torch.empty((B, D), dtype=torch.float32, device=dev)
 
     def step():
-        eng.forward_into(images, mine, vdr.OUT_ENCODER if sam else vdr.OUT_CLS)  # this rank's rows of the gather buffer
+        eng.forward_into(images, mine, vdr.OUT_ENCODER if sam else (vdr.OUT_DENSE if dense else vdr.OUT_CLS))  # this rank's rows of the gather buffer
         if world > 1:
             dist.all_gather_into_tensor(feats, mine)
 
@@ -224,14 +229,14 @@ def main():
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof_all.values()), 3)}
         out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
-               and not a.fp8 else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
-                     else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} CLS-feature extraction"),
+               and not a.fp8 and not dense else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
+                     else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} {'dense-descriptor' if dense else 'CLS-feature'} extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": ("fp8 (MX e4m3 qkv/fc1/fc2" + ("/proj" if a.fp8 >= 2 else "") + ", bf16 elsewhere)") if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
                                        f"[{total},64,64,256] fp32" if sam else
-                                       f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, CLS-token extraction -> [{total},{D}] fp32")
+                                       f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, {'dense per-patch descriptors' if dense else 'CLS-token extraction'} -> [{total},{D}] fp32")
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "micro_batch": a.micro_batch, "streams": a.streams},
