@@ -100,6 +100,8 @@ def main():
                          "dtype); 2: the out-projection too")
     ap.add_argument("--out", choices=["cls", "dense"], default="cls",
                     help="cls: [N, D] CLS features (headline); dense: [N, n*D] per-patch descriptors (BASELINE config 4)")
+    ap.add_argument("--input", choices=["bf16", "fp32"], default="bf16",
+                    help="dtype of the resident input images (the reference feeds fp32; SURVEY §8d asks for both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
@@ -137,7 +139,7 @@ def main():
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
     images = torch.rand(B, 3, ocfg.img, ocfg.img, generator=g)  # synthetic [0,1)
-    images = (images if sam else images.to(torch.bfloat16)).to(dev)  # the reference feeds MedSAM fp32 slices
+    images = (images if (sam or a.input == "fp32") else images.to(torch.bfloat16)).to(dev)  # the reference feeds fp32
     total = B * world
     dense = a.out == "dense" and not sam
     if sam:  # dense descriptor maps [N, 64, 64, 256] fp32, flattened to rows for the gather
@@ -239,7 +241,7 @@ def main():
                                        f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, {'dense per-patch descriptors' if dense else 'CLS-token extraction'} -> [{total},{D}] fp32")
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
-                          "weights": "random-init (seed 1)", "micro_batch": a.micro_batch, "streams": a.streams},
+                          "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
                "roofline": roof, "kernels": kern}
