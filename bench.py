@@ -231,7 +231,7 @@ def main():
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof_all.values()), 3)}
         out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
-               and not a.fp8 and not dense else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" if sam
+               and not a.fp8 and not dense else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" + (" fp8 weights" if a.fp8 else "") if sam
                      else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} {'dense-descriptor' if dense else 'CLS-feature'} extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

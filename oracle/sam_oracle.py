@@ -27,7 +27,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .vit_oracle import _r, gelu_erf, layer_norm
+from .vit_oracle import _q, _r, _wq, gelu_erf, layer_norm
 
 
 @dataclass
@@ -134,7 +134,7 @@ def sam_attention(x, w, p, heads, emulate=False):
     """x [Bw, S, S, D] (one window or the whole grid per batch entry)."""
     Bw, S, _, D = x.shape
     dh = D // heads
-    qkv = _r(x.reshape(Bw, S * S, D) @ _r(w[p + "qkv.weight"], emulate).t() + w[p + "qkv.bias"], emulate)
+    qkv = _r(x.reshape(Bw, S * S, D) @ _wq(w[p + "qkv.weight"], emulate).t() + w[p + "qkv.bias"], emulate)
     q, k, v = qkv.reshape(Bw, S * S, 3, heads, dh).permute(2, 0, 3, 1, 4)  # [Bw, H, N, dh]
     attn = (q * (dh ** -0.5)) @ k.transpose(-1, -2)
     Rh, Rw = rel_table(S, w[p + "rel_pos_h"]), rel_table(S, w[p + "rel_pos_w"])
@@ -148,7 +148,7 @@ def sam_attention(x, w, p, heads, emulate=False):
     l = pexp.sum(dim=-1, keepdim=True)
     o = (_r(pexp, emulate) @ v) / l if emulate else (pexp / l) @ v
     o = _r(o.transpose(1, 2).reshape(Bw, S, S, D), emulate)
-    return o @ _r(w[p + "proj.weight"], emulate).t() + w[p + "proj.bias"]
+    return o @ _r(w[p + "proj.weight"], bool(emulate)).t() + w[p + "proj.bias"]  # the out-projection stays bf16 (fp8 level 1)
 
 
 def layer_norm_2d(x_nhwc, gamma, beta, eps):
@@ -158,7 +158,8 @@ def layer_norm_2d(x_nhwc, gamma, beta, eps):
 
 @torch.no_grad()
 def sam_forward(cfg: SamCfg, w, images, emulate_bf16=False):
-    """[B,3,img,img] -> dict(tokens [B,g,g,D] after the blocks, out [B,C,g,g] after the neck)."""
+    """[B,3,img,img] -> dict(tokens [B,g,g,D] after the blocks, out [B,C,g,g] after the neck).
+    emulate_bf16="mx": additionally the MX-fp8 quantisation points of the fp8 path (qkv / fc1 / fc2 operands)."""
     em = emulate_bf16
     images = images.to(torch.float32)
     B = images.shape[0]
@@ -169,16 +170,16 @@ def sam_forward(cfg: SamCfg, w, images, emulate_bf16=False):
     x = _r(x.reshape(B, g, g, D) + w["pos_embed"], em)
     for i in range(cfg.layers):
         pfx = f"blocks.{i}."
-        h = _r(layer_norm(x, w[pfx + "norm1.weight"], w[pfx + "norm1.bias"], cfg.ln_eps), em)
+        h = _q(layer_norm(x, w[pfx + "norm1.weight"], w[pfx + "norm1.bias"], cfg.ln_eps), em)
         if i in cfg.global_idx:
             a = sam_attention(h, w, pfx + "attn.", cfg.heads, em)
         else:
             hw, pad_hw = window_partition(h, cfg.window)
             a = window_unpartition(sam_attention(hw, w, pfx + "attn.", cfg.heads, em), cfg.window, pad_hw, (g, g))
         x = _r(x + a, em)
-        h = _r(layer_norm(x, w[pfx + "norm2.weight"], w[pfx + "norm2.bias"], cfg.ln_eps), em)
-        u = _r(gelu_erf(h @ _r(w[pfx + "mlp.fc1.weight"], em).t() + w[pfx + "mlp.fc1.bias"]), em)
-        x = _r(x + u @ _r(w[pfx + "mlp.fc2.weight"], em).t() + w[pfx + "mlp.fc2.bias"], em)
+        h = _q(layer_norm(x, w[pfx + "norm2.weight"], w[pfx + "norm2.bias"], cfg.ln_eps), em)
+        u = _q(gelu_erf(h @ _wq(w[pfx + "mlp.fc1.weight"], em).t() + w[pfx + "mlp.fc1.bias"]), em)
+        x = _r(x + u @ _wq(w[pfx + "mlp.fc2.weight"], em).t() + w[pfx + "mlp.fc2.bias"], em)
     tokens = x
     C = cfg.out_chans
     y = _r(x, em) @ _r(w["neck.0.weight"].reshape(C, D), em).t()

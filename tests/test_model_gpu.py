@@ -401,11 +401,11 @@ def test_full_batch_properties_at_baseline_size():
 
 
 # ---- SAM / MedSAM image encoder (the reference's default backbone) ----------------
-def _sam_engine(cfg, w):
+def _sam_engine(cfg, w, fp8=0):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=3, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, has_cls=False, has_pos=True, ln_eps=cfg.ln_eps, window=cfg.window,
-                       global_blocks=tuple(cfg.global_idx), neck_chans=cfg.out_chans)
+                       global_blocks=tuple(cfg.global_idx), neck_chans=cfg.out_chans, fp8=fp8)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -433,6 +433,30 @@ def test_sam_encoder_small(name, cfgargs, batch):
     assert out.shape == (batch, g, g, cfg.out_chans)
     _gate(out, ref["out"].permute(0, 2, 3, 1), emu["out"].permute(0, 2, 3, 1), gate_l2(cfg.layers) + 4e-3,
           gate_l2(cfg.layers) + 4e-3, f"sam {name} neck output")
+
+
+@pytest.mark.parametrize("cfgargs,batch", [
+    (dict(img=160, patch=16, dim=64, heads=1, layers=3, mlp_hidden=128, window=4, global_idx=(1,), out_chans=64), 3),
+    (dict(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64), 2),
+])
+def test_sam_encoder_fp8(cfgargs, batch):
+    """fp8 (qkv / fc1 / fc2 as MX-fp8) on the SAM encoder: LayerNorm -> MX in window-partition order with zero
+    padding rows, the un-partitioning out-projection stays bf16."""
+    import vdr
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(**cfgargs)
+    w = so.make_weights(cfg, seed=21, scale=0.05)
+    x = so.make_images(cfg, batch, seed=22)
+    ref = so.sam_forward(cfg, w, x)
+    emx = so.sam_forward(cfg, w, x, emulate_bf16="mx")
+    e = _sam_engine(cfg, w, fp8=1)
+    g = cfg.grid
+    tok = e.forward(x.cuda(), vdr.OUT_TOKENS)
+    _gate_fp8(tok, ref["tokens"].reshape(batch, g * g, cfg.dim), emx["tokens"].reshape(batch, g * g, cfg.dim), cfg.layers,
+              "sam fp8 tokens")
+    out = e.forward(x.cuda(), vdr.OUT_ENCODER)
+    _gate_fp8(out, ref["out"].permute(0, 2, 3, 1), emx["out"].permute(0, 2, 3, 1), cfg.layers, "sam fp8 neck output")
+    assert torch.equal(out, e.forward(x.cuda(), vdr.OUT_ENCODER))
 
 
 def test_sam_golden_transformers_crosscheck(golden_dir):

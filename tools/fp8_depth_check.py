@@ -24,3 +24,16 @@ for name, B in (("vit_base16_224", 4), ("dinov2_giant14_224", 2)):
             cos = float(torch.nn.functional.cosine_similarity(g2, r2, dim=-1).min())
             print(f"{name:20s} L={cfg.layers:2d} {('fp8=%d' % fp8) if fp8 else 'bf16 '} {key:5s}: rel L2 {rel:.3e}  min row cosine {cos:.5f}", flush=True)
         del m
+
+# the reference's default backbone: SAM ViT-B image encoder at 1024^2, one slice
+from oracle import sam_oracle as so
+w = so.make_weights(so.SAM_VIT_B, seed=1)
+x = so.make_images(so.SAM_VIT_B, 1, seed=3)
+ref = so.sam_forward(so.SAM_VIT_B, w, x)["out"].permute(0, 2, 3, 1)
+for fp8 in (0, 1):
+    m = vdr.load_model("medsam", weights=w, fp8=fp8)
+    got = m.engine.forward(x.cuda(), vdr.OUT_ENCODER, torch.float32).float().cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    cos = float(torch.nn.functional.cosine_similarity(got.reshape(-1, 256), ref.reshape(-1, 256), dim=-1).min())
+    print(f"medsam (SAM ViT-B 1024^2) L=12 {('fp8=%d' % fp8) if fp8 else 'bf16 '} neck : rel L2 {rel:.3e}  min pixel cosine {cos:.5f}", flush=True)
+    del m

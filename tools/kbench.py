@@ -56,7 +56,7 @@ def main():
             print(f"gemm {name:5s} M{M} N{N} K{K} variant {v}: {med:8.3f} ms (min {mn:.3f})  {tf:7.1f} TFLOP/s", flush=True)
         del x, W, out
     qkv = torch.randn(M, 3 * D, device=dev).bfloat16()
-    for v in (3, 2, 12, 22):
+    for v in (3, 2, 1, 12, 22):
         med, mn = timeit(lambda: ops.attention(qkv, a.batch, a.seq, H, variant=v))
         tf = 4.0 * a.seq * a.seq * 64 * H * a.batch / (med * 1e-3) / 1e12
         res[f"attention_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}

@@ -112,10 +112,19 @@ template <int NP>
 __global__ __launch_bounds__(256) void ln_mx_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, int64_t rows, int D,
                                                     uint8_t* __restrict__ q, uint8_t* __restrict__ s,
-                                                    int64_t rows_pad) {
+                                                    int64_t rows_pad, int win_ws, int win_g) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
+  int64_t orow = r;
+  if (win_ws > 0) {
+    // SAM window partition of the output rows (as layernorm_kernel): token (b, y, x) -> window-major order
+    const int g = win_g, ws = win_ws, nw = (g + ws - 1) / ws;
+    const int64_t b = r / (g * g);
+    const int rem = (int)(r - b * g * g);
+    const int y = rem / g, x = rem - y * g;
+    orow = ((b * nw + y / ws) * nw + x / ws) * (int64_t)(ws * ws) + (y % ws) * ws + (x % ws);
+  }
   float v[NP][4];
   float sum = 0.0f;
 #pragma unroll
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(256) void ln_mx_kernel(const bf16_t* __restrict__ x
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) * invD + eps);
-  const int64_t srow = (r & ~(int64_t)63) + mx_perm((int)(r & 63));
+  const int64_t srow = (orow & ~(int64_t)63) + mx_perm((int)(orow & 63));
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int c = k * 256 + lane * 4;
@@ -167,22 +176,22 @@ __global__ __launch_bounds__(256) void ln_mx_kernel(const bf16_t* __restrict__ x
     const int sb = mx_scale_byte(amax);
     const float inv = mx_inv_scale(sb);
     if (ok) {
-      *reinterpret_cast<uint32_t*>(q + r * D + c) = pack_fp8x4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+      *reinterpret_cast<uint32_t*>(q + orow * D + c) = pack_fp8x4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
       if ((lane & 7) == 0) s[(int64_t)(c >> 5) * rows_pad + srow] = (uint8_t)sb;
     }
   }
 }
 
 hipError_t launch_ln_mx(const void* x, const float* gamma, const float* beta, float eps, int64_t rows, int D, void* q,
-                        void* scales, hipStream_t st) {
+                        void* scales, hipStream_t st, int win_ws, int win_g, int64_t out_rows) {
   if (rows <= 0 || D <= 0 || (D & 31) || D > 2048) return hipErrorInvalidValue;
   const int np = (D + 255) / 256;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  const int64_t rp = mx_rows_pad(rows);
+  const int64_t rp = mx_rows_pad(out_rows > 0 ? out_rows : rows);  // rows of the MX tensor the scales belong to
 #define VDR_LNMX(NP)                                                                                              \
   case NP:                                                                                                        \
     hipLaunchKernelGGL((ln_mx_kernel<NP>), grid, block, 0, st, (const bf16_t*)x, gamma, beta, eps, rows, D,      \
-                       (uint8_t*)q, (uint8_t*)scales, rp);                                                        \
+                       (uint8_t*)q, (uint8_t*)scales, rp, win_ws, win_g);                                         \
     break;
   switch (np) {
     VDR_LNMX(1) VDR_LNMX(2) VDR_LNMX(3) VDR_LNMX(4) VDR_LNMX(5) VDR_LNMX(6) VDR_LNMX(7) VDR_LNMX(8)

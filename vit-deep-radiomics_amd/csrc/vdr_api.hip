@@ -560,6 +560,43 @@ int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, 
 }
 
 // L transformer blocks over x [M = mb*ntok rows]; leaves the result in w.x
+// tile configuration of the MX-fp8 GEMM per class and shape (VDR_MX_VARIANT overrides)
+int mx_variant_for(int cls, int64_t M, int N) {
+  static const int forced = env_int("VDR_MX_VARIANT", -1);
+  if (forced >= 0) return forced;
+  if (((M + 127) / 128) * ((N + 255) / 256) < 256) return 2;  // small problem: 128x128 tiles
+  if (cls == VDR_K_GEMM_QKV) return 0;
+  return M >= 16384 ? 0 : 1;  // measured (tools/mx_bench.py): 256x256 tiles win at ViT-g's M = 8224
+}
+
+// one linear on the block-scaled fp8 MFMA: MX operands (aq, as) x (wq, wsc); cs != NULL -> MX output
+int gemm_mx(vdr_model* m, hipStream_t s, int cls, const void* aq, const void* as, const void* wq, const void* wsc,
+            const float* bias, const void* resid, const float* gamma, void* C, void* cs, int64_t M, int N, int K, int ldc,
+            int epi) {
+  GemmArgs g{};
+  g.A = aq;
+  g.a_scale = as;
+  g.W = wq;
+  g.w_scale = wsc;
+  g.bias = bias;
+  g.resid = resid;
+  g.gamma = gamma;
+  g.C = C;
+  g.c_scale = cs;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldw = K;
+  g.ldc = ldc;
+  g.ldr = ldc;
+  g.omap = identity_map();
+  const double outb = cs ? 1.0 : 2.0;
+  Scope sc(m, s, cls, 2.0 * M * N * K, (double)M * K + (double)N * K + (double)M * ldc * (resid ? 2 * outb : outb));
+  VDR_TRY(launch_gemm_mx(g, epi, mx_variant_for(cls, M, N), s), "gemm_mx");
+  return VDR_OK;
+}
+
 int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, const int* lens = nullptr, int len_add = 0) {
   const vdr_config& c = m->cfg;
   const int D = c.dim, F = c.mlp_hidden, H = c.heads;
@@ -572,46 +609,14 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
     // operands); the residual stream and the attention arithmetic stay bf16 / fp32.
     const int N1 = sw ? 2 * F : F;
     const bool proj_mx = c.fp8 >= 2;  // fp8 = 1: qkv / fc1 / fc2; fp8 = 2: the out-projection (and the attention output) too
-    auto mx_variant = [&](int cls, int N) {
-      static const int forced = env_int("VDR_MX_VARIANT", -1);
-      if (forced >= 0) return forced;
-      if (((M + 127) / 128) * ((N + 255) / 256) < 256) return 2;  // small problem: 128x128 tiles
-      if (cls == VDR_K_GEMM_QKV) return 0;
-      return M >= 16384 ? 0 : 1;  // measured (tools/mx_bench.py): 256x256 tiles win at ViT-g's M = 8224
-    };
-    auto gemm_mx = [&](int cls, const void* aq, const void* as, const void* wq, const void* wsc, const float* bias,
-                       const void* resid, const float* gamma, void* C, void* cs, int N, int K, int ldc, int epi) -> int {
-      GemmArgs g{};
-      g.A = aq;
-      g.a_scale = as;
-      g.W = wq;
-      g.w_scale = wsc;
-      g.bias = bias;
-      g.resid = resid;
-      g.gamma = gamma;
-      g.C = C;
-      g.c_scale = cs;
-      g.M = M;
-      g.N = N;
-      g.K = K;
-      g.lda = K;
-      g.ldw = K;
-      g.ldc = ldc;
-      g.ldr = ldc;
-      g.omap = identity_map();
-      const double outb = cs ? 1.0 : 2.0;
-      Scope sc(m, s, cls, 2.0 * M * N * K, (double)M * K + (double)N * K + (double)M * ldc * (resid ? 2 * outb : outb));
-      VDR_TRY(launch_gemm_mx(g, epi, mx_variant(cls, N), s), "gemm_mx");
-      return VDR_OK;
-    };
     for (int i = 0; i < c.layers; ++i) {
       const LayerW& L = m->layers[i];
       {
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n1w, L.n1b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
       }
-      if ((rc = gemm_mx(VDR_K_GEMM_QKV, w.h, w.hs, L.qkv_q, L.qkv_s, L.bqkv, nullptr, nullptr, w.qkv, nullptr, 3 * D, D,
-                        3 * D, EPI_BIAS)))
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_QKV, w.h, w.hs, L.qkv_q, L.qkv_s, L.bqkv, nullptr, nullptr, w.qkv, nullptr, M, 3 * D,
+                        D, 3 * D, EPI_BIAS)))
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -619,7 +624,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, proj_mx ? w.os : nullptr, lens, len_add), "attention");
       }
       if (proj_mx) {
-        if ((rc = gemm_mx(VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, D, D, D,
+        if ((rc = gemm_mx(m, s, VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, M, D, D, D,
                           EPI_BIAS_RESID)))
           return rc;
       } else if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) {
@@ -629,10 +634,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
       }
-      if ((rc = gemm_mx(VDR_K_GEMM_FC1, w.h, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, N1, D, F,
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC1, w.h, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, M, N1, D, F,
                         sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
         return rc;
-      if ((rc = gemm_mx(VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, w.x, L.ls2, w.x, nullptr, D, F, D, EPI_BIAS_RESID)))
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, w.x, L.ls2, w.x, nullptr, M, D, F, D, EPI_BIAS_RESID)))
         return rc;
     }
     return VDR_OK;
@@ -741,6 +746,10 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
   const int groups = D / 64;
   int rc;
   VDR_TRY(hipMemsetAsync(w.h, 0, (size_t)mb * wtok * D * 2, s), "memset(window padding)");
+  // fp8 (qkv / fc1 / fc2 on the block-scaled MFMA; out-projection, rel-pos GEMM, attention and neck stay bf16): the
+  // padding rows of the windowed MX activation are zero payload (memset above) under zeroed, i.e. finite, scales
+  const bool fp8 = c.fp8 != 0;
+  if (fp8) VDR_TRY(hipMemsetAsync(w.hs, 0, mx_scale_bytes(w.Mp, D), s), "memset(window padding scales)");
   for (int i = 0; i < c.layers; ++i) {
     const LayerW& L = m->layers[i];
     const bool glob = (c.global_mask >> i) & 1;
@@ -748,7 +757,15 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
     const int64_t T = glob ? M : (int64_t)mb * wtok;
     const int nb = glob ? mb : mb * nw * nw;
     char* hbuf = glob ? w.hg : w.h;
-    {
+    if (fp8) {
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
+        VDR_TRY(launch_ln_mx(w.x, L.n1w, L.n1b, c.ln_eps, M, D, hbuf, w.hs, s, glob ? 0 : ws, g, T), "layernorm_mx(window)");
+      }
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_QKV, hbuf, w.hs, L.qkv_q, L.qkv_s, L.bqkv, nullptr, nullptr, w.qkv, nullptr, T, 3 * D, D,
+                        3 * D, EPI_BIAS)))
+        return rc;
+    } else {
       LnArgs a{};
       a.x = w.x;
       a.in_bf16 = 1;
@@ -767,8 +784,8 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
       }
       Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 4);
       VDR_TRY(launch_layernorm(a, s), "layernorm(window)");
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS))) return rc;
     }
-    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS))) return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)S * S * S * S * 64.0 * H * nb + 2.0 * T * H * relpos_npad(S) * 64,
                2.0 * (double)T * 4 * D);
@@ -800,6 +817,19 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
       }
       Scope sc(m, s, VDR_K_GEMM_PROJ, 2.0 * T * D * D, 2.0 * ((double)T * D + (double)D * D + 2.0 * M * D));
       VDR_TRY(launch_gemm(ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ, ga.M, ga.N), s), "proj gemm");
+    }
+    if (fp8) {
+      {
+        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
+        VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.hg, w.hs, s), "layernorm_mx");
+      }
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC1, w.hg, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, M, F, D, F,
+                        EPI_BIAS_GELU)))
+        return rc;
+      if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, w.x, nullptr, w.x, nullptr, M, D, F, D,
+                        EPI_BIAS_RESID)))
+        return rc;
+      continue;
     }
     if (m->ln_fuse) {
       {
@@ -906,8 +936,7 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
     return fail(nullptr, VDR_ERR_UNSUPPORTED, "token models carry no learned pos_embed");
   }
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
-  if (c.fp8 && (!c.pre_ln || c.window > 0))
-    return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models without windowed attention only");
+  if (c.fp8 && !c.pre_ln) return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models only");
   if (c.window > 0) {
     const int g = c.patch ? c.img / c.patch : 0;
     auto side_ok = [](int v) { return v == 4 || v == 7 || v == 10 || v == 14 || v == 64; };

@@ -90,8 +90,9 @@ static inline size_t mx_scale_bytes(int64_t rows, int K) { return (size_t)mx_row
 hipError_t launch_mx_quant(const void* x, int64_t rows, int K, int64_t ldx, void* q, void* scales, hipStream_t s);
 hipError_t launch_mx_dequant(const void* q, const void* scales, int64_t rows, int K, float* y, hipStream_t s);
 //   LayerNorm over bf16 rows, MX out
+//   win_ws > 0: output rows in SAM window-partition order (out_rows = rows of that padded layout)
 hipError_t launch_ln_mx(const void* x, const float* gamma, const float* beta, float eps, int64_t rows, int D, void* q,
-                        void* scales, hipStream_t s);
+                        void* scales, hipStream_t s, int win_ws = 0, int win_g = 0, int64_t out_rows = 0);
 //   C = epi(A . W^T) with MX operands; variant 0: 128x256 tile / 8 waves, 1: 256x256 / 16 waves, 2: 128x128 / 4 waves
 hipError_t launch_gemm_mx(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 
