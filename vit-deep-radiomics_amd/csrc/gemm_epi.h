@@ -46,6 +46,12 @@ struct GemmK {
 };
 
 // Epilogue math for 4 consecutive output columns n..n+3 of output row m (v2 = SwiGLU gate partner).
+// value of lane i + N inside the 16-lane DPP row (0 past the row end)
+template <int N>
+VDR_DEV float dpp_row_shl(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
 template <int EPI>
 VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, int n) {
   if (m >= p.M || n >= p.N) return;
@@ -363,11 +369,14 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
           if (p.ln_part) {
             // the 8 lanes of a row hold its 64 columns of this block: (sum, sumsq) -> one slot per
             // (row, 64-column group), written exactly once: no atomics, no zeroing, deterministic
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {
-              s1 += __shfl_xor(s1, o, 64);
-              s2 += __shfl_xor(s2, o, 64);
-            }
+            // lane c8 == 0 of each 8-lane group collects the group: three DPP row-shift adds (lane i += lane i+4, +2,
+            // +1 inside its 16-lane row) instead of three ds_bpermute round trips per value
+            s1 += dpp_row_shl<4>(s1);
+            s2 += dpp_row_shl<4>(s2);
+            s1 += dpp_row_shl<2>(s1);
+            s2 += dpp_row_shl<2>(s2);
+            s1 += dpp_row_shl<1>(s1);
+            s2 += dpp_row_shl<1>(s2);
             const int grp = (n_base + jp * 64) >> 6;
             if (c8 == 0 && orow >= 0 && n_base + jp * 64 < p.N) {
               float* dst = p.ln_part + ((int64_t)grp * p.part_stride + orow) * 2;
