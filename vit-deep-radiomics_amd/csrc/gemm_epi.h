@@ -111,12 +111,40 @@ VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, i
 // (a store wave-instruction costs ~80-100 cycles of the CU's store path whatever its width, so the
 // epilogue is written with the widest ones).
 typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+// Per-column epilogue constants of one octet (bias, LayerNorm-fold column sums, LayerScale): they depend on the
+// column only, so epilogue_lds fetches them once per 64-column block instead of once per row step.
+struct EpiCols {
+  f32x4 b0, b1, c0, c1, g0, g1;
+  bool have = false;
+};
+VDR_DEV EpiCols load_epi_cols(const GemmK& p, int n) {
+  EpiCols e;
+  e.have = true;
+  const int nn = n < p.N ? n : 0;  // out-of-range octets are never stored; keep the address valid
+  const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+  e.b0 = e.b1 = e.c0 = e.c1 = z;
+  e.g0 = e.g1 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+  if (p.bias) {
+    e.b0 = *reinterpret_cast<const f32x4*>(p.bias + nn);
+    e.b1 = *reinterpret_cast<const f32x4*>(p.bias + nn + 4);
+  }
+  if (p.ln_stats) {
+    e.c0 = *reinterpret_cast<const f32x4*>(p.colsum + nn);
+    e.c1 = *reinterpret_cast<const f32x4*>(p.colsum + nn + 4);
+  }
+  if (p.gamma) {
+    e.g0 = *reinterpret_cast<const f32x4*>(p.gamma + nn);
+    e.g1 = *reinterpret_cast<const f32x4*>(p.gamma + nn + 4);
+  }
+  return e;
+}
 // EPI_*_MX (gemm_mx.hip only): the same epilogue math, output re-quantised to MX-fp8
 constexpr int epi_base(int e) { return e == EPI_BIAS_GELU_MX ? EPI_BIAS_GELU : e == EPI_SWIGLU_MX ? EPI_SWIGLU : e; }
 constexpr bool epi_mx_out(int e) { return e == EPI_BIAS_GELU_MX || e == EPI_SWIGLU_MX; }
 template <int EPI>
 VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m, int n, float& sum1, float& sum2,
-                        float mu = 0.0f, float rs = 1.0f) {
+                        float mu = 0.0f, float rs = 1.0f, const EpiCols& ec = EpiCols()) {
   constexpr int E = epi_base(EPI);
   constexpr bool MXO = epi_mx_out(EPI);
   (void)MXO;
@@ -147,8 +175,11 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   if (p.ln_stats) {
     // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
     // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.colsum + n);
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 4);
+    f32x4 c0 = ec.c0, c1 = ec.c1;
+    if (!ec.have) {
+      c0 = *reinterpret_cast<const f32x4*>(p.colsum + n);
+      c1 = *reinterpret_cast<const f32x4*>(p.colsum + n + 4);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] = rs * (v[e] - mu * c0[e]);
@@ -165,8 +196,11 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     }
   }
   if (p.bias) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    f32x4 b0 = ec.b0, b1 = ec.b1;
+    if (!ec.have) {
+      b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+      b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] += b0[e];
@@ -192,8 +226,11 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   }
   if (E == EPI_BIAS_RESID) {
     if (p.gamma) {
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(p.gamma + n + 4);
+      f32x4 g0 = ec.g0, g1 = ec.g1;
+      if (!ec.have) {
+        g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);
+        g1 = *reinterpret_cast<const f32x4*>(p.gamma + n + 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] *= g0[e];
@@ -352,6 +389,7 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
       stage_acc_block<TM, TN>(acc, stg, i, jp, lane);
       if (E != EPI_SWIGLU) {
         // 8 lanes per row (8 columns each), 8 rows per instruction: whole 128-B lines, 16-B accesses
+        const EpiCols ec = load_epi_cols(p, n_base + jp * 64 + (lane & 7) * 8);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int row = rr * 8 + (lane >> 3), c8 = lane & 7;
@@ -365,7 +403,7 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
           }
           float s1, s2;
           const int64_t orow = epi_oct<EPI>(p, v, u, m_base + i * 32 + row, n_base + jp * 64 + c8 * 8, s1, s2,
-                                            st_mu[i][rr], st_rs[i][rr]);
+                                            st_mu[i][rr], st_rs[i][rr], ec);
           if (p.ln_part) {
             // the 8 lanes of a row hold its 64 columns of this block: (sum, sumsq) -> one slot per
             // (row, 64-column group), written exactly once: no atomics, no zeroing, deterministic
