@@ -288,11 +288,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
 template <int NT>
 __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_items) {
   constexpr int KEYS = NT * 32;
-  constexpr int VT_STRIDE = NT * 64 + 8;
-  constexpr int BUF = KEYS * 128 + 64 * VT_STRIDE;
+  constexpr int BUF = 2 * KEYS * 128;                 // K image + V image, both [key][64 d] rows of 128 B
   constexpr int NCW = 7;                              // waves == query tiles served per item
-  constexpr int KPW = (NT * 4 + NCW - 1) / NCW;       // K pieces (8 rows) per wave
-  constexpr int VPW = (NT * 128 + NCW * 64 - 1) / (NCW * 64);  // V items per lane
+  constexpr int PPW = (NT * 8 + NCW - 1) / NCW;       // 8-row DMA pieces (K: NT*4, then V: NT*4) per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -305,56 +303,30 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
   const int nqt = (p.seq + 31) >> 5;
   const float sc = 0.125f * 1.44269504088896341f;
 
-  // ---- staging of one item, split in an issue half and a write half -------------------------------
-  bf16x8 sv0[VPW], sv1[VPW];
+  // ---- staging of one item: K and V rows straight into LDS by global_load_lds, no registers -------
+  //   K: 16-B chunk ^ ((key >> 1) & 7)            (ds_read_b128 row reads of the 32x32x16 operand)
+  //   V: 16-B chunk ^ (((key >> 1) & 1) << 2)     (ds_read_b64_tr_b16 blocks of 4 keys x 16 d: the two even / odd keys
+  //                                                of a block land in different halves of their 32 banks)
+  // V stays row-major: the transposed read hands every lane V[key0 .. key0+3][d] -- the P.V operand -- so the
+  // register-staged transpose (32 VGPRs and 16 ds_write_b32 per thread and item) of the first version is gone.
   auto stage_issue = [&](int item, char* buf) {
     const int b = item / p.heads;
     const int hd = item - b * p.heads;
     const bf16_t* kb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64 + HD;
-    const bf16_t* vb = kb + HD;
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
+    for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NCW;
-      if (piece < NT * 4) {
-        const int r = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+      if (piece < NT * 8) {
+        const int isv = piece >= NT * 4;
+        const int r = (piece - isv * NT * 4) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (isv ? (((r >> 1) & 1) << 2) : ((r >> 1) & 7));
         const int key = r < p.seq ? r : p.seq - 1;
-        glds16(kb + (int64_t)key * p.ld_qkv + c * 8, buf + piece * 1024);
+        glds16(kb + isv * HD + (int64_t)key * p.ld_qkv + c * 8, buf + piece * 1024);
       }
-    }
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-      int it = tid + i * (NCW * 64);
-      it = it < NT * 128 ? it : NT * 128 - 1;
-      const int dc = (it >> 3) & 7;
-      const int kp = (it & 7) | ((it >> 6) << 3);
-      const int key0 = 2 * kp;
-      const int k0 = key0 < p.seq ? key0 : p.seq - 1;
-      const int k1 = key0 + 1 < p.seq ? key0 + 1 : p.seq - 1;
-      sv0[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k0 * p.ld_qkv + dc * 8);
-      sv1[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k1 * p.ld_qkv + dc * 8);
     }
   };
-  auto stage_write = [&](char* buf) {
-    char* sVt = buf + KEYS * 128;
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-      const int it = tid + i * (NCW * 64);
-      if (it < NT * 128) {
-        const int dc = (it >> 3) & 7;
-        const int kp = (it & 7) | ((it >> 6) << 3);
-        const int key0 = 2 * kp;
-        const bool ok0 = key0 < p.seq, ok1 = key0 + 1 < p.seq;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          bf16x2 pr;
-          pr[0] = ok0 ? sv0[i][e] : (bf16_t)0.0f;
-          pr[1] = ok1 ? sv1[i][e] : (bf16_t)0.0f;
-          *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // K pieces landed, V^T written
+  auto stage_write = [&](char*) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own K / V pieces landed, own LDS reads done
   };
 
   // Q fragments of this wave's query tile (B operand of S^T = K.Q^T): 4 x 16 B straight from global
@@ -375,7 +347,16 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     const int b = item / p.heads;
     const int hd = item - b * p.heads;
     const char* sK = buf + l31 * 128;
-    const char* sVt = buf + KEYS * 128 + l31 * VT_STRIDE + hh * 8;
+    // transposed V read: lane 4q+p of its 16-lane group addresses key row q, d columns 4p..4p+3 of a 4 x 16 block and
+    // receives d column (lane & 15) of the 4 keys; groups: d half (lane >> 4) & 1, key offset 4 hh
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
+    const int vkey = 4 * hh + tq;  // + 16 it (+ 8 for the high half): multiples of 8 keep (key >> 1) & 1
+    const __attribute__((address_space(3))) char* sV =
+        (const __attribute__((address_space(3))) char*)(buf + KEYS * 128) + vkey * 128 + 8 * (tp & 1);
+    int vch[2];
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
     int kch[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kch[ks] = ((2 * ks + hh) ^ swz) * 16;
@@ -427,9 +408,8 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     auto read_v = [&](int it) {
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) {
-        const char* vrow = sVt + nd * 32 * VT_STRIDE + it * 32;
-        vlo[nd] = *reinterpret_cast<const bf16x4*>(vrow);
-        vhi[nd] = *reinterpret_cast<const bf16x4*>(vrow + 16);
+        vlo[nd] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + vch[nd]));
+        vhi[nd] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + 8 * 128 + vch[nd]));
       }
     };
     auto make_p = [&](int it, int set) {
@@ -498,7 +478,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
 
 template <int NT>
 static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = 2 * ((size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8));
+  constexpr size_t lds = 2 * (size_t)(2 * NT * 32 * 128);
   auto fn = attn_persist_kernel<NT>;
   hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
