@@ -33,6 +33,8 @@ struct GemmK {
   int a_rpg;
   int64_t a_gs, a_is;
   int out_f32;
+  int nt_store = 0;  // large write-once outputs (fc1's activation, qkv): non-temporal stores keep them from evicting the
+                     // A / W panels the main loops of the resident workgroups stream from L2
   // MX-fp8 operands (gemm_mx.hip): A / W point at e4m3 payloads, lda / ldw are in bytes
   const uint8_t* sA = nullptr;
   const uint8_t* sW = nullptr;
@@ -303,7 +305,8 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   }
   int oc = n;
   if (E == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
-  *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
+  if (p.nt_store) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc));
+  else *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
   return orow;
 }
 

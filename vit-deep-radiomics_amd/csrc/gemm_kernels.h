@@ -839,6 +839,11 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.a_gs = a.a_gs;
   k.a_is = a.a_is;
   k.out_f32 = a.out_f32;
+  {
+    static const int nt_env = [] { const char* e = getenv("VDR_GEMM_NT"); return e && *e ? atoi(e) : -1; }();
+    const bool big = (double)a.M * (double)a.ldc * 2.0 >= 128e6 && !a.resid;  // write-once output larger than half the Infinity Cache
+    k.nt_store = nt_env >= 0 ? nt_env : (big ? 1 : 0);
+  }
   k.ln_stats = a.ln_stats;
   k.colsum = a.colsum;
   k.ln_part = a.ln_part;
