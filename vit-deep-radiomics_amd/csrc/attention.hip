@@ -83,10 +83,9 @@ VDR_DEV void attn_store_row(const AttnK& p, const f32x16 (&o)[2], float inv, boo
 template <int NT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   constexpr int KEYS = NT * 32;
-  constexpr int VT_STRIDE = NT * 64 + 8;  // bytes per d-row of Vt
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;                 // KEYS * 128 B
-  char* sVt = smem + KEYS * 128;   // 64 * VT_STRIDE B
+  char* sVt = smem + KEYS * 128;   // V image, KEYS * 128 B, row-major like K
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -94,6 +93,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   const int hh = lane >> 5;
   const int l31 = lane & 31;
   const int swz = (lane >> 1) & 7;
+  // transposed V read: lane 4q+p of a 16-lane group addresses key row q, d columns 4p..4p+3 of a 4 x 16 block and
+  // receives d column (lane & 15) of the 4 keys (groups: d half (lane >> 4) & 1, key offset 4 hh)
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
+  const int vkey = 4 * hh + tq;
+  const __attribute__((address_space(3))) char* sVtr =
+      (const __attribute__((address_space(3))) char*)sVt + vkey * 128 + 8 * (tp & 1);
+  int vch[2];
+#pragma unroll
+  for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
 
   const int b = blockIdx.x / p.heads;
   const int hd = blockIdx.x - b * p.heads;
@@ -138,37 +147,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
       key = key < p.seq ? key : p.seq - 1;
       glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
     }
-    // V^T: item = (key pair, 8-wide d chunk); all row loads of a thread are issued before its first
-    // LDS write, then each key pair is packed into one dword per d
-    constexpr int NIT = (NT * 128 + 255) / 256;
-    bf16x8 v0[NIT], v1[NIT];
+    // V rows the same way (row-major, chunk ^ (((key >> 1) & 1) << 2)), consumed by ds_read_b64_tr_b16 in process():
+    // no register-staged transpose; rows past the sequence repeat the last key (their P is exp(-inf) = 0)
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int it = tid + i * 256;
-      const int dc = (it >> 3) & 7;
-      const int kp = (it & 7) | ((it >> 6) << 3);
-      const int key0 = kc0 + 2 * kp;
-      const int k0 = key0 < p.seq ? key0 : p.seq - 1;
-      const int k1 = key0 + 1 < p.seq ? key0 + 1 : p.seq - 1;
-      v0[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k0 * p.ld_qkv + dc * 8);
-      v1[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)k1 * p.ld_qkv + dc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int it = tid + i * 256;
-      if (it < NT * 128) {
-        const int dc = (it >> 3) & 7;
-        const int kp = (it & 7) | ((it >> 6) << 3);
-        const int key0 = kc0 + 2 * kp;
-        const bool ok0 = key0 < p.seq, ok1 = key0 + 1 < p.seq;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          bf16x2 pr;
-          pr[0] = ok0 ? v0[i][e] : (bf16_t)0.0f;
-          pr[1] = ok1 ? v1[i][e] : (bf16_t)0.0f;
-          *reinterpret_cast<bf16x2*>(sVt + (dc * 8 + e) * VT_STRIDE + kp * 4) = pr;
-        }
-      }
+    for (int q = 0; q < NT; ++q) {
+      const int piece = wave * NT + q;
+      const int r = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (((r >> 1) & 1) << 2);
+      int key = kc0 + r;
+      key = key < p.seq ? key : p.seq - 1;
+      glds16(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -227,12 +215,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
           lsum += pv;  // fp32 row sum (same order in the persistent kernel: results are bitwise equal)
           pf[j] = (bf16_t)pv;
         }
-        const int koff = (t * 32 + s2 * 16 + 4 * hh) * 2;
 #pragma unroll
         for (int nd = 0; nd < 2; ++nd) {
-          const char* vrow = sVt + (nd * 32 + l31) * VT_STRIDE + koff;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 16);
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sVtr + (t * 32 + s2 * 16) * 128 + vch[nd]));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sVtr + (t * 32 + s2 * 16 + 8) * 128 + vch[nd]));
           bf16x8 vf;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -497,7 +483,7 @@ static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
 
 template <int NT>
 static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = (size_t)NT * 32 * 128 + 64 * (size_t)(NT * 64 + 8);
+  constexpr size_t lds = 2 * (size_t)NT * 32 * 128;  // K image + V image
   auto fn = attn_kernel<NT>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
