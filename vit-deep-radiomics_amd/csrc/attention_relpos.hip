@@ -63,8 +63,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   constexpr int KEYS = NT * 32;
   static_assert(!MULTI || (S == 64 && NT == 4), "the chunked form assumes 128-key chunks = two rows of a 64-wide grid");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sVt = smem + KEYS * 128;
+  constexpr int BUF = 2 * KEYS * 128;  // K image + V image; the chunked (MULTI) form ping-pongs between two of them
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,8 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
   const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
   const int vkey = 4 * hh + tq;
-  const __attribute__((address_space(3))) char* sVtr =
-      (const __attribute__((address_space(3))) char*)sVt + vkey * 128 + 8 * (tp & 1);
+  const int vbase = KEYS * 128 + vkey * 128 + 8 * (tp & 1);  // byte offset of this lane's V address inside a buffer
   int vch[2];
 #pragma unroll
   for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
@@ -128,7 +126,9 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     l_run = 0.0f;
   };
 
-  auto stage = [&](int kc0) {
+  auto stage_issue = [&](int kc0, char* buf) {
+    char* sK = buf;
+    char* sVt = buf + KEYS * 128;
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int piece = wave * NT + q;
@@ -149,11 +149,15 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
       key = key < p.seq ? key : p.seq - 1;
       glds16(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
     }
+  };
+  auto stage_wait = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
-  auto process = [&](int kc0, bool rescale) {
+  auto process = [&](int kc0, bool rescale, const char* buf) {
+    const char* sK = buf;
+    const __attribute__((address_space(3))) char* sVtr = (const __attribute__((address_space(3))) char*)buf + vbase;
     if (MULTI) {
       // this chunk covers grid rows kc0/64 and kc0/64 + 1
       relh[0] = relrow[-(kc0 >> 6)];
@@ -259,20 +263,23 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   };
 
   if (!MULTI) {
-    stage(0);
+    stage_issue(0, smem);
+    stage_wait();
     for (int qt = qt_begin + wave; qt < qt_end; qt += 4) {
       load_q(qt);
-      process(0, false);
+      process(0, false, smem);
       store(qt);
     }
   } else {
     const int qt = qt_begin + wave;
     const bool valid = qt < qt_end;
     load_q(valid ? qt : qt_begin);
+    // double-buffered: chunk c+1 streams into the other buffer while chunk c is processed; one barrier per chunk
+    stage_issue(0, smem);
     for (int c = 0; c < p.n_chunks; ++c) {
-      if (c) __syncthreads();
-      stage(c * KEYS);
-      if (valid) process(c * KEYS, c > 0);
+      stage_wait();
+      if (c + 1 < p.n_chunks) stage_issue((c + 1) * KEYS, smem + ((c + 1) & 1) * BUF);
+      if (valid) process(c * KEYS, c > 0, smem + (c & 1) * BUF);
     }
     if (valid) store(qt);
   }
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
 
 template <int NT, int S, bool MULTI>
 static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)NT * 32 * 128;  // K image + V image
+  constexpr size_t lds = (MULTI ? 2 : 1) * 2 * (size_t)NT * 32 * 128;  // (K image + V image) x 1 or 2 buffers
   auto fn = attn_relpos_kernel<NT, S, MULTI>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
