@@ -498,3 +498,20 @@ def test_medsam_vit_b_1024_geometry_and_boundary():
     sam_sd = {("image_encoder." + k).replace(".mlp.fc1.", ".mlp.lin1.").replace(".mlp.fc2.", ".mlp.lin2."): v for k, v in w.items()}
     sam_sd["prompt_encoder.dummy"] = torch.zeros(1)
     assert sorted(from_sam_state_dict(sam_sd)) == sorted(w)
+
+
+@pytest.mark.parametrize("fp8", [0, 1])
+def test_batch_size_sweep_rows_do_not_depend_on_the_batch(fp8):
+    """Odd batch sizes (1, 2, 3, 5, 17, 65) on a small ViT, bf16 and fp8: every image's CLS / dense rows are bitwise
+    what the same image gives in any other batch (edge tiles of every GEMM shape, ragged attention launches)."""
+    import vdr
+    cfg = SMALL["p14_d192"]
+    w = vo.make_weights(cfg, seed=5, scale=0.05)
+    e = _engine(cfg, w, fp8=fp8)
+    x = vo.make_images(cfg, 65, seed=6).cuda()
+    full_cls = e.forward(x, vdr.OUT_CLS)
+    full_dense = e.forward(x, vdr.OUT_DENSE)
+    for B in (1, 2, 3, 5, 17):
+        sel = torch.arange(B) * 3 % 65
+        assert torch.equal(e.forward(x[sel], vdr.OUT_CLS), full_cls[sel]), B
+        assert torch.equal(e.forward(x[sel], vdr.OUT_DENSE), full_dense[sel]), B
