@@ -101,6 +101,8 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
     S = vol.shape[2]
     medsam = model.model_name == "medsam"
     features_list, mask_list = [], []
+    rb = mb = None
+    pending = []
     for s0 in range(0, S, max_batch):
         s1 = min(S, s0 + max_batch)
         x = prep.prepare_slices(vol[:, :, s0:s1], side=model.cfg.img, flip=flip, device=model.device)
@@ -109,11 +111,19 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
         else:
             g = model.cfg.img // model.cfg.patch
             maps = model.engine.forward(x, L.OUT_PATCH_EMBED, torch.float32).reshape(s1 - s0, g, g, model.cfg.dim)
-        rb = roi_box(maps.shape[1:3], bigger_c)
-        crops = crop_maps(maps.contiguous(), rb).cpu().numpy()
+        if rb is None:  # the boxes depend on the (cropped) union mask only: once per volume, not once per slice
+            rb = roi_box(maps.shape[1:3], bigger_c)
+            mb = roi_box(mask_c.shape[0:2], bigger_c)
+        crops = crop_maps(maps.contiguous(), rb)
+        host = torch.empty(crops.shape, dtype=crops.dtype, pin_memory=True)
+        host.copy_(crops, non_blocking=True)   # D2H queued behind the crop; the next batch is enqueued without a host sync
+        pending.append((host, s0, s1))
+    torch.cuda.current_stream(model.device).synchronize()  # ONE synchronisation per volume
+    for host, s0, s1 in pending:
+        arr = host.numpy()
         for i in range(s1 - s0):
-            features_list.append(crops[i])
-            mask_list.append(extract_roi(mask_c[:, :, s0 + i] > 0, bigger_c))
+            features_list.append(arr[i])
+            mask_list.append(crop_image(mask_c[:, :, s0 + i] > 0, *mb))
     return features_list, mask_list
 
 
