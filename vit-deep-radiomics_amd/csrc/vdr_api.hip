@@ -735,7 +735,7 @@ hipError_t relpos_products(const void* qkv, const void* table, float* T, int64_t
   ga.a_gs = (int64_t)3 * heads * 64;
   ga.a_is = 64;
   ga.out_f32 = 1;
-  return launch_gemm(ga, EPI_BIAS, ga.N <= 128 ? 20 : 19, s);
+  return launch_gemm(ga, EPI_BIAS, ga.N <= 128 ? 24 : 22, s);  // ring3: 128x128 tiles for the 64-column window table, 128x256 for the global one
 }
 
 int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, char* out, bool tokens_only) {
