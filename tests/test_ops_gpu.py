@@ -86,7 +86,7 @@ def test_linear_exact_integers_catches_layout_bugs(ops):
     assert torch.equal(y.float().cpu(), _bf(W).float().t())
 
 
-@pytest.mark.parametrize("variant", list(range(1, 25)))
+@pytest.mark.parametrize("variant", list(range(1, 26)))
 def test_linear_every_tile_variant_exact(ops, variant):
     """Every tile configuration the library can be asked for (legacy single/double-stage kernels, the ring
     kernels, ring2 = 32x32x16 MFMA, ring3 = 16x16x32 MFMA) on integer data: bit-exact, with bias, GELU-free

@@ -13,7 +13,7 @@ namespace vdr {
 hipError_t launch_gemm_legacy(const GemmArgs& a, int epilogue, int variant, hipStream_t s);  // gemm_legacy.hip
 hipError_t launch_gemm_ring2(const GemmArgs& a, int epilogue, int variant, hipStream_t s);   // gemm_ring2.hip
 
-int gemm_num_variants() { return 25; }
+int gemm_num_variants() { return 26; }
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
@@ -32,6 +32,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
       return launch_cfg<4, 4, 2, 2, 33>(a, epilogue, s);  // ring3: 256x256, 16 waves, 3 x 32 KB
     case 24:
       return launch_cfg<2, 2, 2, 2, 33>(a, epilogue, s);  // ring3: 128x128, 4 waves, 3 x 16 KB, 3 WG/CU
+    case 25:
+      return launch_cfg<2, 2, 2, 2, 43>(a, epilogue, s);  // ring3k: 128x128 tile, 8 waves = 2 K-groups x (2x2), 3 x 32 KB
     default:
       return hipErrorInvalidValue;
   }

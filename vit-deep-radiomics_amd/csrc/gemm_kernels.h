@@ -616,6 +616,153 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
   epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// -------------------------------------------------------------------------------------------------
+// ring3 with the K loop split across two wave groups of one workgroup (small problems: a single 1024^2 SAM slice is
+// M = 4096, i.e. fewer 128 x 128 tiles than CUs, every tile a serial chain of K/32 units on ONE wave per SIMD).
+// 8 waves per 128 x 128 tile: group g = wave >> 2 consumes unit 2s + g of "super-unit" s (64 K), so the serial chain
+// halves and every SIMD holds two waves whose MFMA and LDS phases interleave; group 1 hands its accumulators to group
+// 0 through LDS at the end (deterministic: fixed order, no atomics), group 0 runs the usual LDS-staged epilogue.
+// -------------------------------------------------------------------------------------------------
+template <int NST, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ring3k_kernel(GemmK p) {
+  constexpr int TM = 2, TN = 2;
+  constexpr int BM = 128, BN = 128, NW = 8;
+  constexpr int UNIT = (BM + BN) * 64;  // 16 KB: one 32-K unit
+  constexpr int SUPER = 2 * UNIT;       // one 64-K super-unit: unit of group 0, then unit of group 1
+  constexpr int G = 4;                  // DMA instructions per wave and super-unit
+  static_assert((NST - 1) * G <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wg = xcd_remap(blockIdx.x, p.nwg);
+  int tm, tn;
+  tile_of(p, wg, tm, tn);
+  const int64_t m0 = (int64_t)tm * BM;
+  const int n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+
+  // staging: wave w brings 16 rows of A and 16 rows of W of BOTH units of a super-unit
+  const int srow = lane >> 2, spc = lane & 3;
+  const bf16_t* a_src;
+  const bf16_t* b_src;
+  {
+    const int r = wave * 16 + srow;
+    const int c = spc ^ ((r >> 2) & 3);
+    int64_t gr = m0 + r;
+    gr = gr < p.M ? gr : p.M - 1;
+    const int64_t aoff = p.a_rpg > 0 ? (gr / p.a_rpg) * p.a_gs + (gr % p.a_rpg) * p.a_is : gr * p.lda;
+    a_src = p.A + aoff + c * 8;
+    int gn = n0 + r;
+    gn = gn < p.N ? gn : p.N - 1;
+    b_src = p.W + (int64_t)gn * p.ldw + c * 8;
+  }
+  const int r15 = lane & 15;
+  const int chq = ((lane >> 4) ^ ((lane >> 2) & 3)) * 16;
+  const int a_base = kg * UNIT + (wm * 64 + r15) * 64 + chq;
+  const int b_base = kg * UNIT + BM * 64 + (wn * 64 + r15) * 64 + chq;
+
+  Acc16 acc;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.t[j][i][e] = 0.0f;
+
+  const int nsteps = p.K >> 6;  // super-units
+  auto stage = [&](int slot) {
+    char* d = smem + slot * SUPER;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      glds16(a_src + g * 32, d + g * UNIT + wave * 1024);
+      glds16(b_src + g * 32, d + g * UNIT + BM * 64 + wave * 1024);
+    }
+    a_src += 64;
+    b_src += 64;
+  };
+  auto ld = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(smem + slot * SUPER + off); };
+  auto retire = [&](int u, int issued_upto) {
+    const int younger = issued_upto - u;
+    if (younger >= NST - 1) {
+      wait_vmcnt<(NST - 1) * G>();
+    } else if (younger == NST - 2 && NST >= 3) {
+      wait_vmcnt<(NST - 2) * G>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  };
+  bf16x8 fb[4], alo[2], ahi[2];
+  int issued = -1;
+#pragma unroll
+  for (int u = 0; u < NST; ++u)
+    if (u < nsteps) {
+      stage(u);
+      issued = u;
+    }
+  retire(0, issued);
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = ld(0, b_base + j * 1024);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) alo[i] = ld(0, a_base + i * 1024);
+  int slot = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    const int nslot = slot + 1 == NST ? 0 : slot + 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc.t[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], alo[i], acc.t[j][i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ahi[i] = ld(slot, a_base + (2 + i) * 1024);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (s + 1 < nsteps) {
+      retire(s + 1, issued);
+      __builtin_amdgcn_s_barrier();
+      if (s + NST < nsteps) {
+        stage(slot);
+        issued = s + NST;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) alo[i] = ld(nslot, a_base + i * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc.t[j][2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], ahi[i], acc.t[j][2 + i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      fb[j] = ld(nslot, b_base + j * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    slot = nslot;
+  }
+
+  // K reduction across the two groups: group 1 -> LDS -> group 0 (layout [register][lane] f32x4: conflict-free)
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(smem) + w4 * (16 * 64);
+  if (kg == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(j * 4 + i) * 64 + lane] = acc.t[j][i];
+  }
+  __syncthreads();
+  if (kg == 1) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 o = red[(j * 4 + i) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc.t[j][i][e] += o[e];
+    }
+  epilogue_lds<EPI, TM, TN>(p, acc, smem + 65536 + w4 * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 template <int WAVES_M, int WAVES_N, int NST, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring3_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -747,7 +894,9 @@ inline int g_gemm_split = 0;  // VDR_GEMM_SPLIT=1 enables the mixed-height last 
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, int PIPE, int E>
 static auto launch_pick() -> void (*)(GemmK) {
-  if constexpr (PIPE >= 30)
+  if constexpr (PIPE >= 40)
+    return gemm_ring3k_kernel<PIPE - 40, E>;
+  else if constexpr (PIPE >= 30)
     return gemm_ring3_kernel<WAVES_M, WAVES_N, PIPE - 30, E>;
   else if constexpr (PIPE >= 20)
     return gemm_ring2_kernel<WAVES_M, WAVES_N, TM, TN, PIPE - 20, E>;
@@ -859,12 +1008,13 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     k.epi_lds = epi_lds;
   }
 
-  const dim3 grid((unsigned)k.nwg), block(WAVES_M * WAVES_N * 64);
-  constexpr int RING_SLOTS = PIPE >= 30 ? PIPE - 30 : PIPE - 20;
+  const dim3 grid((unsigned)k.nwg), block(PIPE >= 40 ? 512 : WAVES_M * WAVES_N * 64);  // ring3k: two wave groups per tile
+  constexpr int RING_SLOTS = PIPE >= 40 ? 2 * (PIPE - 40) : PIPE >= 30 ? PIPE - 30 : PIPE - 20;
   const size_t lds_ring2 = (size_t)(BM + BN) * 64 * RING_SLOTS > (size_t)WAVES_M * WAVES_N * 32 * 272
                                ? (size_t)(BM + BN) * 64 * RING_SLOTS
                                : (size_t)WAVES_M * WAVES_N * 32 * 272;
-  const size_t lds = PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
+  const size_t lds_k = lds_ring2 > (size_t)65536 + 4 * 32 * 272 ? lds_ring2 : (size_t)65536 + 4 * 32 * 272;  // ring3k: reduction + staging
+  const size_t lds = PIPE >= 40 ? lds_k : PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
 #define VDR_LAUNCH(E)                                                                             \
   case E: {                                                                                       \
     auto fn = launch_pick<WAVES_M, WAVES_N, TM, TN, PIPE, E>();                                   \

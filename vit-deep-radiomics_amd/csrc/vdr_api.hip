@@ -482,8 +482,11 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   // small problems (a single 1024^2 SAM slice is M = 4096): fewer 128x256 tiles than CUs -> 128x128 tiles
   // (measured, MedSAM batch 1: fc2 0.72 -> 0.57 ms, proj 0.35 -> 0.31 ms per forward)
   if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) {
-    static const int small = env_int("VDR_GEMM_VARIANT_SMALL", 24);
-    return small;  // ring3 128x128, 4 waves, 3 workgroups per CU
+    static const int small = env_int("VDR_GEMM_VARIANT_SMALL", -1);
+    if (small >= 0) return small;
+    // ring3 128x128 tiles; with a narrow output (proj / fc2: N = 768) even those are fewer than CUs, so the K loop is
+    // split across two wave groups of the workgroup (variant 25: fc2 at M = 4096 42.7 -> 37.6 us, proj 17.7 -> 16.6)
+    return N <= 1024 ? 25 : 24;
   }
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
