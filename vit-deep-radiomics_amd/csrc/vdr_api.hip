@@ -484,9 +484,11 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) {
     static const int small = env_int("VDR_GEMM_VARIANT_SMALL", -1);
     if (small >= 0) return small;
-    // ring3 128x128 tiles; with a narrow output (proj / fc2: N = 768) even those are fewer than CUs, so the K loop is
-    // split across two wave groups of the workgroup (variant 25: fc2 at M = 4096 42.7 -> 37.6 us, proj 17.7 -> 16.6)
-    return N <= 1024 ? 25 : 24;
+    // ring3 128x128 tiles.  Variant 25 (the K loop split across two wave groups of the workgroup) is 2 % faster on a
+    // MedSAM batch-1 forward (fc2 at M = 4096 42.7 -> 37.6 us) but sums K in a different order than the big-batch
+    // kernels, so a row would no longer be bitwise independent of the batch it is in: opt-in only
+    // (VDR_GEMM_VARIANT_SMALL=25), the default keeps rows batch-invariant.
+    return 24;
   }
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
