@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 2
+#define VDR_ABI_VERSION 3
 
 typedef enum {
   VDR_OK = 0,
@@ -52,7 +52,7 @@ typedef enum {
   VDR_ERR_UNSUPPORTED = -7   /* config outside what the kernels cover       */
 } vdr_status;
 
-typedef enum { VDR_F32 = 0, VDR_BF16 = 1, VDR_F64 = 2, VDR_I16 = 3 } vdr_dtype; /* F64 / I16: pre-processing inputs only */
+typedef enum { VDR_F32 = 0, VDR_BF16 = 1, VDR_F64 = 2, VDR_I16 = 3, VDR_U8 = 4 } vdr_dtype; /* F64 / I16 / U8: pre-processing only */
 
 typedef enum { VDR_ACT_GELU = 0, /* exact erf GELU: models_archs.py:133, timm/DINOv2 Mlp */
                VDR_ACT_SWIGLU = 1 /* DINOv2 ViT-g SwiGLUFFN (w12 / w3)                   */
@@ -242,6 +242,19 @@ int vdr_op_hu_to_rgb(const void* hu, int in_dtype, int64_t n, void* rgb, void* s
  *   src fp32 [batch, H, W, C] -> dst fp32 [batch, crop_h, crop_w, C], window origin (y0, x0), fully inside */
 int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C, int y0, int x0, int crop_h,
                     int crop_w, void* stream);
+/* rotate_image (tfds_dense_descriptor.py:327-350): scipy.ndimage.rotate(vol, angle, axes=(0, 1), reshape=False,
+ * mode='nearest') = scipy.ndimage.affine_transform(plane, matrix, offset, order=3, mode='nearest', prefilter=True)
+ * on every (H, W) plane of the volume; float64 arithmetic in SciPy's operation order (bit-identical results).
+ *   src      [h, w, planes] (planes = slices [x channels], fastest) fp64 (VDR_F64), fp32 (VDR_F32) or a boolean mask
+ *            as bytes 0 / 1 (VDR_U8); out has the same shape and dtype
+ *   matrix   2 x 2 row-major, offset 2: input coordinate = matrix . output index + offset (SciPy's convention;
+ *            rotate() passes [[cos, sin], [-sin, cos]] and in_center - matrix . out_center)
+ *   clip01   1: clip the float result to [0, 1] (the np.clip of rotate_image); masks: out = (unsigned char) t,
+ *            SciPy's store into a boolean output, so `out > 0` is rotate_image's mask
+ *   scratch  vdr_affine_cubic_scratch_bytes(h, w, planes) bytes: the edge-padded float64 spline coefficients */
+size_t vdr_affine_cubic_scratch_bytes(int h, int w, int64_t planes);
+int vdr_op_affine_cubic(const void* src, int dtype, int h, int w, int64_t planes, const double* matrix,
+                        const double* offset, void* out, int clip01, void* scratch, void* stream);
 
 /* F.scaled_dot_product_attention over a packed qkv activation — the core of
  * nn.MultiheadAttention (models_archs.py:130) / Attention.forward of the ViTs.

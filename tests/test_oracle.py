@@ -156,3 +156,32 @@ def test_prep_oracle_matches_reference_goldens(golden_dir):
     for tag, (w, l) in {"w800_l40": (800, 40), "w1500_lm600": (1500, -600), "w350_l50": (350, 50)}.items():
         for nm in ("i16", "f32"):
             assert np.array_equal(po.apply_window_ct(wv["ct_" + nm], w, l), wv[f"{tag}_{nm}"])
+
+
+def test_rotate_oracle_is_bit_identical_to_scipy_and_goldens(golden_dir):
+    """oracle/rotate_oracle.py restates scipy.ndimage.rotate(order 3, mode 'nearest', axes (0, 1), reshape False)
+    operation for operation: bitwise equal to SciPy itself on float64 / float32 / bool volumes (square, non-square,
+    4-D), and to the committed fixtures of the reference's rotate_image calls (make_golden_rotate.py)."""
+    from scipy.ndimage import rotate
+    from oracle import rotate_oracle as ro
+    rng = np.random.default_rng(7)
+    for shape, dt in (((40, 40, 3), np.float64), ((37, 52, 2), np.float64), ((30, 34, 2, 3), np.float64),
+                      ((33, 41, 2), np.float32)):
+        v = rng.random(shape).astype(dt)
+        for ang in (45, 90, 135, 30):
+            ref = rotate(v, ang, axes=(0, 1), reshape=False, mode="nearest")
+            got = ro.rotate_planes(v, ang)
+            assert got.dtype == ref.dtype and np.array_equal(ref, got), (shape, dt, ang)
+    m = np.zeros((64, 56, 4), bool)
+    m[20:40, 15:35, 1:3] = True
+    m[5:9, 40:50, 0] = True
+    for ang in (45, 90, 135):
+        assert np.array_equal(rotate(m, ang, axes=(0, 1), reshape=False, mode="nearest"), ro.rotate_planes(m, ang))
+    g = np.load(os.path.join(golden_dir, "rotate_cases.npz"))
+    for name in g["names"]:
+        img, mask = g[f"{name}_img"], g[f"{name}_mask"]
+        for ang in (45, 90, 135):
+            ri, rm = ro.rotate_image(img, mask, ang)
+            assert np.array_equal(ri, g[f"{name}_img_{ang}"]) and np.array_equal(rm, g[f"{name}_mask_{ang}"]), (name, ang)
+    ri, rm = ro.rotate_image(img, mask, 0)
+    assert np.array_equal(ri, img) and np.array_equal(rm, mask)

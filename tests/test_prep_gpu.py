@@ -145,3 +145,88 @@ def test_extract_patient_features_augmentation_loop():
     f2, m2 = pipeline.generate_features(model, np.ascontiguousarray(img[:, ::-1]), np.ascontiguousarray(mask[:, ::-1]))
     for i in range(S):
         assert np.array_equal(feats[2 * S + i], f2[i]) and np.array_equal(masks[2 * S + i], m2[i])
+
+
+def test_rotate_volume_bit_identical_to_scipy_and_goldens(golden_dir):
+    """rotate_image (tfds_dense_descriptor.py:327-350) on the GPU: bitwise equal to the committed fixtures of the
+    reference's SciPy calls, to the oracle, and to scipy.ndimage.rotate itself (float64 / float32 / bool volumes,
+    non-square planes, a 4-D colour volume, an arbitrary angle, a single plane)."""
+    from scipy.ndimage import rotate
+    from vdr import prep, pipeline
+    from oracle import rotate_oracle as ro
+    g = _load(golden_dir, "rotate_cases.npz")
+    for name in g["names"]:
+        img, mask = g[f"{name}_img"], g[f"{name}_mask"]
+        for ang in (45, 90, 135):
+            ri, rm = pipeline.rotate_image(img, mask, ang)  # numpy in -> numpy out
+            assert ri.dtype == img.dtype and rm.dtype == np.bool_
+            assert np.array_equal(ri, g[f"{name}_img_{ang}"]), (name, ang)
+            assert np.array_equal(rm, g[f"{name}_mask_{ang}"]), (name, ang)
+    rng = np.random.default_rng(11)
+    for shape, dt in (((96, 96, 17), np.float64), ((70, 101, 5), np.float64), ((50, 47, 3, 3), np.float64),
+                      ((64, 80, 9), np.float32), ((33, 35, 1), np.float64)):
+        v = rng.random(shape).astype(dt)
+        for ang in (45, 135, 30):
+            want = rotate(v, ang, axes=(0, 1), reshape=False, mode="nearest")
+            got = prep.rotate_volume(v, ang).cpu().numpy()
+            assert got.dtype == want.dtype and np.array_equal(got, want), (shape, dt, ang)
+            assert np.array_equal(got, ro.rotate_planes(v, ang))
+    m = np.zeros((90, 84, 6), bool)
+    m[30:61, 22:50, 1:5] = True
+    m[8:14, 60:75, 0] = True
+    for ang in (45, 90, 135):
+        want = rotate(m, ang, axes=(0, 1), reshape=False, mode="nearest")
+        got = prep.rotate_volume(m, ang).cpu().numpy()
+        assert got.dtype == np.bool_ and np.array_equal(got, want), ang
+    # angle 0: copies; device tensors in -> device tensors out
+    img = torch.rand(20, 20, 2, dtype=torch.float64, device="cuda")
+    msk = torch.zeros(20, 20, 2, dtype=torch.bool, device="cuda")
+    ri, rm = pipeline.rotate_image(img, msk, 0)
+    assert ri.is_cuda and torch.equal(ri, img) and ri.data_ptr() != img.data_ptr() and torch.equal(rm, msk)
+    ri, rm = pipeline.rotate_image(img, msk, 90)
+    assert ri.is_cuda and rm.is_cuda and rm.dtype == torch.bool
+
+
+def test_rotate_volume_ct_sized_slice_stack():
+    """A CT-sized stack (512 x 512 x 24 float64 in [0, 1] + its nodule mask): image and mask bitwise equal to
+    SciPy; clip01 == np.clip of the reference."""
+    from scipy.ndimage import rotate
+    from vdr import prep
+    rng = np.random.default_rng(12)
+    vol = rng.random((512, 512, 24))
+    yy, xx = np.mgrid[0:512, 0:512]
+    mask = np.repeat((((yy - 300) ** 2 + (xx - 210) ** 2) < 40 ** 2)[:, :, None], 24, axis=2)
+    want = np.clip(rotate(vol, 45, axes=(0, 1), reshape=False, mode="nearest"), 0, 1)
+    got = prep.rotate_volume(vol, 45, clip01=True).cpu().numpy()
+    assert np.array_equal(got, want)
+    wm = rotate(mask, 45, axes=(0, 1), reshape=False, mode="nearest") > 0
+    gm = prep.rotate_volume(mask, 45).cpu().numpy()
+    assert np.array_equal(gm, wm) and 0 < gm.sum() < mask.sum()  # the truncating bool store thins the mask
+
+
+def test_extract_patient_features_rotations_match_scipy_path():
+    """The augmentation loop with a non-trivial angle: the GPU-rotated pass equals generate_features on the volume
+    SciPy rotates on the CPU (what the reference does), bit for bit."""
+    import vdr
+    from scipy.ndimage import rotate
+    from vdr import pipeline
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64)
+    w = so.make_weights(cfg, seed=23)
+    vc = vdr.VdrConfig(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, has_cls=False, window=7,
+                       global_blocks=(1,), neck_chans=64)
+    model = vdr.VitDescriptorModel(vc, w, "medsam", torch.device("cuda"))
+    model.model_name = "medsam"
+    rng = np.random.default_rng(10)
+    H, W, S = 64, 60, 4
+    img = rng.random((H, W, S))
+    mask = np.zeros((H, W, S), dtype=bool)
+    mask[18:38, 22:44, 1:3] = True
+    feats, masks, df = pipeline.extract_patient_features(model, img, mask, "P2", 1, "stanford_dataset", "ct",
+                                                         np.array([1.0, 1.0, 1.0]), flips=(None,), angles=(0, 45))
+    assert len(feats) == 2 * S and list(df["angle"]) == [0] * S + [45] * S
+    im45 = np.clip(rotate(img, 45, axes=(0, 1), reshape=False, mode="nearest"), 0, 1)
+    m45 = rotate(mask, 45, axes=(0, 1), reshape=False, mode="nearest") > 0
+    f2, m2 = pipeline.generate_features(model, im45, m45)
+    for i in range(S):
+        assert np.array_equal(feats[S + i], f2[i]) and np.array_equal(masks[S + i], m2[i])

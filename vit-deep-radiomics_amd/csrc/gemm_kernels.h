@@ -626,7 +626,7 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
 template <int NST, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_ring3k_kernel(GemmK p) {
   constexpr int TM = 2, TN = 2;
-  constexpr int BM = 128, BN = 128, NW = 8;
+  constexpr int BM = 128, BN = 128;
   constexpr int UNIT = (BM + BN) * 64;  // 16 KB: one 32-K unit
   constexpr int SUPER = 2 * UNIT;       // one 64-K super-unit: unit of group 0, then unit of group 1
   constexpr int G = 4;                  // DMA instructions per wave and super-unit

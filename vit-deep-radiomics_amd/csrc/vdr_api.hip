@@ -1373,6 +1373,26 @@ int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C
   return VDR_OK;
 }
 
+size_t vdr_affine_cubic_scratch_bytes(int h, int w, int64_t planes) {
+  if (h <= 0 || w <= 0 || planes <= 0) return 0;
+  return affine_cubic_scratch_bytes(h, w, planes);
+}
+
+int vdr_op_affine_cubic(const void* src, int dtype, int h, int w, int64_t planes, const double* matrix, const double* offset,
+                        void* out, int clip01, void* scratch, void* stream) {
+  if (!src || !out || !matrix || !offset || !scratch) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (h < 2 || w < 2 || planes <= 0) return fail(nullptr, VDR_ERR_INVALID, "affine_cubic: planes of at least 2 x 2");
+  const int dt = dtype == VDR_F64 ? 0 : dtype == VDR_F32 ? 1 : dtype == VDR_U8 ? 2 : -1;
+  if (dt < 0) return fail(nullptr, VDR_ERR_UNSUPPORTED, "affine_cubic: fp64, fp32 or uint8 (boolean mask) volume");
+  if ((int64_t)(h + 24) * (w + 24) * planes >= ((int64_t)1 << 31) * 256)
+    return fail(nullptr, VDR_ERR_UNSUPPORTED, "affine_cubic: volume too large for one launch");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_affine_cubic(src, dt, h, w, planes, matrix, offset, out, clip01, (double*)scratch, (hipStream_t)stream),
+         "affine_cubic");
+  return VDR_OK;
+}
+
 size_t vdr_mx_scale_bytes(int64_t rows, int K) { return rows > 0 && K > 0 ? mx_scale_bytes(rows, K) : 0; }
 
 int vdr_op_mx_quantize(const void* x, int64_t rows, int K, void* q, void* scales, void* stream) {

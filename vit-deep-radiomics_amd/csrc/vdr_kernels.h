@@ -104,6 +104,11 @@ hipError_t launch_window_ct(const void* ct, int in_i16, int64_t n, double width,
 hipError_t launch_hu_to_rgb(const void* hu, int dtype, int64_t n, void* rgb, hipStream_t s);
 hipError_t launch_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C, int y0, int x0, int ch, int cw,
                            hipStream_t s);
+// scipy.ndimage.affine_transform(order=3, mode='nearest', prefilter=True) on every (H, W) plane of an [H, W, planes]
+// volume (rotate.hip); dtype 0 f64, 1 f32, 2 u8 (boolean mask, truncating store); scratch = affine_cubic_scratch_bytes
+size_t affine_cubic_scratch_bytes(int H, int W, int64_t planes);
+hipError_t launch_affine_cubic(const void* src, int dtype, int H, int W, int64_t planes, const double* matrix,
+                               const double* offset, void* out, int clip01, double* scratch, hipStream_t s);
 
 static inline int relpos_npad(int S) { return 2 * ((2 * S - 1 + 31) / 32 * 32); }
 hipError_t launch_relpos_pack(const float* rel_h, const float* rel_w, void* table, int S, hipStream_t s);

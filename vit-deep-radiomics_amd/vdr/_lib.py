@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvdr.so")
 
-VDR_F32, VDR_BF16, VDR_F64, VDR_I16 = 0, 1, 2, 3
+VDR_F32, VDR_BF16, VDR_F64, VDR_I16, VDR_U8 = 0, 1, 2, 3, 4
 ACT_GELU, ACT_SWIGLU = 0, 1
 OUT_CLS, OUT_DENSE, OUT_PATCH_EMBED, OUT_TOKENS, OUT_ENCODER = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
@@ -52,6 +52,8 @@ SYMBOLS = {
     "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),
     "vdr_op_hu_to_rgb": (_I, [_P, _I, _L, _P, _P]),
     "vdr_op_crop_hwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vdr_affine_cubic_scratch_bytes": (C.c_size_t, [_I, _I, _L]),
+    "vdr_op_affine_cubic": (_I, [_P, _I, _I, _I, _L, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _I, _P, _P]),
     "vdr_mx_scale_bytes": (C.c_size_t, [_L, _I]),
     "vdr_op_mx_quantize": (_I, [_P, _L, _I, _P, _P, _P]),
     "vdr_op_mx_dequantize": (_I, [_P, _P, _L, _I, _P, _P]),
@@ -86,7 +88,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vdr_abi_version() != 2:
+    if lib.vdr_abi_version() != 3:
         raise ImportError("libvdr ABI version mismatch")
     _lib = lib
     return lib

@@ -83,7 +83,7 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
     Returns (features_list, mask_list) exactly like the reference: per slice a (h', w', D) float32 array and
     the (h'', w'') bool mask crop.  All S slices go through prepare -> encoder -> ROI crop in batches of
     `max_batch` on the GPU; one D2H per batch of the already-cropped maps."""
-    mask_np = np.asarray(mask_3d)
+    mask_np = mask_3d.cpu().numpy() if isinstance(mask_3d, torch.Tensor) else np.asarray(mask_3d)
     bigger_mask = np.sum(mask_np, axis=-1) > 0
     xmin, ymin, xmax, ymax = extract_coords(bigger_mask, margin=2)
     crop_size = max(xmax - xmin, ymax - ymin) * 2
@@ -179,35 +179,36 @@ def feature_metadata(n_features_per_aug, patient_id, label, dataset_name, modali
 
 
 def rotate_image(image, mask, angle, axes=(0, 1)):
-    """tfds_dense_descriptor.py:327-350 verbatim in behaviour, on the CPU with scipy (cubic-spline rotation is the
-    one pre-processing step that has no GPU kernel here: DESIGN.md §6): image clipped to [0, 1], mask > 0."""
-    image, mask = np.asarray(image), np.asarray(mask)
-    if angle == 0:
-        return image.copy(), mask.copy()
-    from scipy.ndimage import rotate
-    image_rot = np.clip(rotate(image, angle, axes=axes, reshape=False, mode="nearest"), 0, 1)
-    mask_rot = rotate(mask, angle, axes=axes, reshape=False, mode="nearest") > 0
-    return image_rot, mask_rot
+    """tfds_dense_descriptor.py:327-350 on the GPU (prep.rotate_image: SciPy's cubic-spline rotation restated in
+    float64, bit-identical): image clipped to [0, 1], mask > 0.  numpy in -> numpy out (the reference's contract);
+    device tensors in -> device tensors out, which generate_features consumes without another upload."""
+    on_host = not (isinstance(image, torch.Tensor) and image.is_cuda)
+    img, m = prep.rotate_image(image, mask, angle, axes=axes)
+    if on_host:
+        return img.cpu().numpy(), m.cpu().numpy()
+    return img, m
 
 
 def extract_patient_features(model, img_raw, mask_raw, patient_id, label, dataset_name, modality, spatial_res,
                              flips=(None, "horizontal", "vertical"), angles=(0, 45, 90, 135), max_batch=16):
     """The reference's per-patient augmentation loop (tfds_dense_descriptor.py:452-491): for every flip x angle,
     generate_features over the whole volume; returns (all_features, all_masks, metadata DataFrame) ready for
-    save_features / save_metadata.  Flips are host-side views copied once per augmentation, rotations by a non-zero
-    angle go through rotate_image (scipy, CPU) exactly as the reference does; everything after that (resize, encoder,
-    ROI crop) runs batched on the GPU."""
+    save_features / save_metadata.  The volume and its mask are uploaded ONCE; flips (torch.flip), rotations
+    (prep.rotate_image), resize, encoder and ROI crop all run on the GPU, and only the cropped feature maps and the
+    rotated masks (needed for the boxes) come back."""
     all_features, all_masks, counts, augs = [], [], [], []
-    img_np, mask_np = np.asarray(img_raw), np.asarray(mask_raw)
-
-    def flipped(a, flip_type):  # flip_image (:305-324)
-        return a[:, ::-1] if flip_type == "horizontal" else a[::-1] if flip_type == "vertical" else a
+    img = torch.as_tensor(np.asarray(img_raw) if not isinstance(img_raw, torch.Tensor) else img_raw)
+    if img.dtype not in (torch.float32, torch.float64):
+        img = img.to(torch.float64)
+    img = img.to(model.device)
+    mask = torch.as_tensor(np.asarray(mask_raw) if not isinstance(mask_raw, torch.Tensor) else mask_raw).to(model.device)
+    mask = mask if mask.dtype == torch.bool else mask > 0
 
     for flip_type in flips:
-        im_f, m_f = flipped(img_np, flip_type), flipped(mask_np, flip_type)
+        im_f, m_f = prep.flip_image(img, mask, flip_type)  # flip_image (:305-324)
         for angle in angles:
-            im, m = rotate_image(im_f, m_f, angle)
-            feats, fmasks = generate_features(model, np.ascontiguousarray(im), np.ascontiguousarray(m), max_batch=max_batch)
+            im, m = (im_f, m_f) if angle == 0 else prep.rotate_image(im_f, m_f, angle)
+            feats, fmasks = generate_features(model, im, m, max_batch=max_batch)
             all_features += feats
             all_masks += fmasks
             counts.append(len(feats))

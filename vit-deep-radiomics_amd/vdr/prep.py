@@ -10,7 +10,9 @@ Same names, argument meaning and return contracts as the functions they replace;
   flip_image(image, mask, flip_type)    src/tfds_dense_descriptor.py:305-324 (views; prepare_slices(flip=...) folds
                                         the image flip into the resize gather instead)
 
-rotate_image (scipy.ndimage.rotate, cubic spline, :327-350) is NOT implemented on the GPU: it stays upstream.
+  rotate_volume / rotate_image          src/tfds_dense_descriptor.py:327-350 (scipy.ndimage.rotate, cubic spline,
+                                        mode 'nearest', in the (0, 1) plane): float64 on the GPU, bit-identical
+
 There is no CPU fallback: without the HIP library every function raises.
 """
 from __future__ import annotations
@@ -91,3 +93,63 @@ def flip_image(image, mask, flip_type):
     if flip_type == "vertical":
         return image.flip(0), mask.flip(0)
     return image, mask
+
+
+def affine_cubic(vol: torch.Tensor, matrix, offset, clip01=False) -> torch.Tensor:
+    """scipy.ndimage.affine_transform(plane, matrix, offset, order=3, mode='nearest') on every (H, W) plane of a
+    device volume [H, W, ...] (float64, float32 or bool); same shape and dtype out."""
+    lib = L.load()
+    assert vol.is_cuda and vol.dim() >= 2
+    dt = {torch.float64: L.VDR_F64, torch.float32: L.VDR_F32, torch.bool: L.VDR_U8}.get(vol.dtype)
+    if dt is None:
+        raise TypeError(f"affine_cubic: float64, float32 or bool volume, got {vol.dtype}")
+    vol = vol.contiguous()
+    H, W = vol.shape[:2]
+    planes = vol.numel() // (H * W)
+    out = torch.empty_like(vol)
+    if planes == 0:
+        return out
+    scratch = torch.empty(lib.vdr_affine_cubic_scratch_bytes(H, W, planes), dtype=torch.uint8, device=vol.device)
+    import ctypes as C
+    m = (C.c_double * 4)(*[float(v) for v in np.asarray(matrix, dtype=np.float64).reshape(-1)])
+    o = (C.c_double * 2)(*[float(v) for v in np.asarray(offset, dtype=np.float64).reshape(-1)])
+    L.check(lib.vdr_op_affine_cubic(vol.data_ptr(), dt, H, W, planes, m, o, out.data_ptr(), int(bool(clip01)),
+                                    scratch.data_ptr(), _s(vol)))
+    return out
+
+
+def rotation_matrix_offset(shape_hw, angle):
+    """The (matrix, offset) scipy.ndimage.rotate(axes=(0, 1), reshape=False) passes to affine_transform: the same
+    numpy / scipy.special expressions, so the six doubles are the ones SciPy computes."""
+    from scipy import special
+    c, s = special.cosdg(angle), special.sindg(angle)
+    rot = np.array([[c, s], [-s, c]])
+    plane = np.asarray(shape_hw)
+    out_center = rot @ ((plane - 1) / 2)
+    in_center = (plane - 1) / 2
+    return rot, in_center - out_center
+
+
+def rotate_volume(vol, angle, clip01=False, device=None) -> torch.Tensor:
+    """scipy.ndimage.rotate(vol, angle, axes=(0, 1), reshape=False, mode='nearest') for an (H, W, S[, C]) volume
+    (numpy array or tensor; float64 / float32 / bool) on the GPU; returns a device tensor of the same dtype."""
+    t = torch.as_tensor(vol)
+    if t.dtype not in (torch.float64, torch.float32, torch.bool):
+        t = t.to(torch.float64)  # SciPy filters every other dtype in float64 as well; integer stores are not restated
+    t = t.to(device if device is not None else (t.device if t.is_cuda else "cuda"))
+    rot, off = rotation_matrix_offset(t.shape[:2], angle)
+    return affine_cubic(t, rot, off, clip01=clip01)
+
+
+def rotate_image(image, mask, angle, axes=(0, 1), device=None):
+    """rotate_image of the reference: image rotated and clipped to [0, 1], mask rotated and thresholded `> 0`.
+    Returns device tensors (image dtype kept, mask bool); angle 0 returns copies, as the reference does."""
+    if tuple(axes) != (0, 1):
+        raise NotImplementedError("rotate_image: the reference only rotates in the (0, 1) plane")
+    if angle == 0:
+        dev = device if device is not None else "cuda"
+        return torch.as_tensor(image).to(dev).clone(), torch.as_tensor(mask).to(dev).clone()
+    img = rotate_volume(image, angle, clip01=True, device=device)
+    m = torch.as_tensor(mask)
+    m = rotate_volume(m if m.dtype == torch.bool else m.to(torch.bool), angle, device=device)
+    return img, m
