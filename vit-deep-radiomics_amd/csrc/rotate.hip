@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void rot_pad_kernel(const T* __restrict__ src,
   dst[i] = (double)src[((int64_t)y * W + x) * planes + t];
 }
 
-// line l of `lines`: first element at (l / inner) * outer_stride + (l % inner), elements `stride` apart, n of them
+// line l of `lines`: first element at (l / inner) * outer_stride + (l % inner), elements `stride` apart, n of them.
+// The recursions are serial per line, the loads are not: every pass fetches FB elements ahead of the arithmetic
+// (a load never depends on a store of the same pass), so a lane keeps FB rows in flight instead of one.
+constexpr int FB = 8;
+
 __global__ __launch_bounds__(64) void rot_filter_kernel(double* __restrict__ c, int64_t lines, int64_t inner, int64_t outer_stride,
                                                          int64_t stride, int n, double z_n) {
   const int64_t l = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -54,8 +58,22 @@ __global__ __launch_bounds__(64) void rot_filter_kernel(double* __restrict__ c, 
   const double c0 = p[0] * gain;
   double acc = c0 + z_n * (p[(int64_t)(n - 1) * stride] * gain);
   double z_i = z;
-  for (int i = 1; i < n; ++i) {
-    // SciPy accumulates into c[0] in place and its last term reads c[0] itself
+  double f[FB], r[FB];
+  int i = 1;
+  for (; i + FB <= n - 1; i += FB) {  // terms 1 .. n-2: c[i] from the front, c[n-1-i] from the back
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      f[k] = p[(int64_t)(i + k) * stride];
+      r[k] = p[(int64_t)(n - 1 - i - k) * stride];
+    }
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      acc = acc + z_i * (f[k] * gain + z_n * (r[k] * gain));
+      z_i *= z;
+    }
+  }
+  for (; i < n; ++i) {
+    // SciPy accumulates into c[0] in place and its last term (i = n - 1) reads c[0] itself
     const double other = i == n - 1 ? acc : p[(int64_t)(n - 1 - i) * stride] * gain;
     acc = acc + z_i * (p[(int64_t)i * stride] * gain + z_n * other);
     z_i *= z;
@@ -63,13 +81,33 @@ __global__ __launch_bounds__(64) void rot_filter_kernel(double* __restrict__ c, 
   acc = acc * (z / (1.0 - z_n * z_n));
   double prev = acc + c0;
   p[0] = prev;
-  for (int i = 1; i < n; ++i) {
+  i = 1;
+  for (; i + FB <= n; i += FB) {
+#pragma unroll
+    for (int k = 0; k < FB; ++k) f[k] = p[(int64_t)(i + k) * stride];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      prev = f[k] * gain + z * prev;
+      p[(int64_t)(i + k) * stride] = prev;
+    }
+  }
+  for (; i < n; ++i) {
     prev = p[(int64_t)i * stride] * gain + z * prev;
     p[(int64_t)i * stride] = prev;
   }
   prev = prev * (z / (z - 1.0));
   p[(int64_t)(n - 1) * stride] = prev;
-  for (int i = n - 2; i >= 0; --i) {
+  i = n - 2;
+  for (; i - FB + 1 >= 0; i -= FB) {
+#pragma unroll
+    for (int k = 0; k < FB; ++k) f[k] = p[(int64_t)(i - k) * stride];
+#pragma unroll
+    for (int k = 0; k < FB; ++k) {
+      prev = z * (prev - f[k]);
+      p[(int64_t)(i - k) * stride] = prev;
+    }
+  }
+  for (; i >= 0; --i) {
     prev = z * (prev - p[(int64_t)i * stride]);
     p[(int64_t)i * stride] = prev;
   }
