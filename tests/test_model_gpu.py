@@ -515,3 +515,35 @@ def test_batch_size_sweep_rows_do_not_depend_on_the_batch(fp8):
         sel = torch.arange(B) * 3 % 65
         assert torch.equal(e.forward(x[sel], vdr.OUT_CLS), full_cls[sel]), B
         assert torch.equal(e.forward(x[sel], vdr.OUT_DENSE), full_dense[sel]), B
+
+
+@pytest.mark.parametrize("tag", ["tiny", "refdim"])
+def test_golden_reference_bimodal_classifier(golden_dir, tag):
+    """models_archs.TransformerNoduleBimodalClassifier (:38-124) golden vectors made by the reference itself: the
+    drop-in class with the reference's state_dict keys, CT + PET (cross attention), CT only, PET only."""
+    import vdr
+    from oracle import bimodal_oracle as bo
+    g = np.load(os.path.join(golden_dir, f"bimodal_{tag}.npz"), allow_pickle=False)
+    dim, lc, lp = int(g["dim"]), int(g["layers_ct"]), int(g["layers_pet"])
+    rc, rp, hc, hp, ncls = float(g["ratio_ct"]), float(g["ratio_pet"]), int(g["heads_ct"]), int(g["heads_pet"]), int(g["classes"])
+    sd = bo.make_state_dict(dim, int(rc * dim), int(rp * dim), lc, lp, ncls, seed=int(g["seed"]))
+    m = vdr.TransformerNoduleBimodalClassifier(dim, rc, rp, hc, hp, lc, lp, ncls, sd)
+    x_ct, x_pet = torch.from_numpy(g["x_ct"]).cuda(), torch.from_numpy(g["x_pet"]).cuda()
+    L = max(lc, lp) + 1  # encoder depth + the cross-attention / fusion stage
+    for mode, (a, b) in (("both", (x_ct, x_pet)), ("ct", (x_ct, None)), ("pet", (None, x_pet))):
+        out = m(a, b)
+        assert len(out) == 4
+        for name, o in zip(("logits_petct", "cls_petct", "logits_ct", "logits_pet"), out):
+            want = torch.from_numpy(g[f"{mode}_{name}"])
+            assert o.shape == want.shape and o.dtype == torch.float32 and o.is_cuda, (mode, name)
+            if name.startswith("cls"):
+                r, c = _rel_l2(o.cpu(), want), _min_cos(o.cpu(), want)
+                print(f"bimodal_{tag} {mode} {name}: relL2 {r:.3e} min cos {c:.6f}")
+                assert r <= gate_l2(L) and c >= 0.999, (mode, name, r, c)
+            else:
+                err = (o.cpu() - want).abs().max().item()
+                assert err < 3e-2, (mode, name, err)
+    with pytest.raises(AssertionError):
+        m(None, None)
+    # single-modality mode returns the encoder's CLS row: identical to the unimodal engine path
+    assert torch.equal(m(x_ct, None)[1], m.engines["ct"].forward_tokens(x_ct, vdr.OUT_CLS))

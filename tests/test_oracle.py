@@ -185,3 +185,21 @@ def test_rotate_oracle_is_bit_identical_to_scipy_and_goldens(golden_dir):
             assert np.array_equal(ri, g[f"{name}_img_{ang}"]) and np.array_equal(rm, g[f"{name}_mask_{ang}"]), (name, ang)
     ri, rm = ro.rotate_image(img, mask, 0)
     assert np.array_equal(ri, img) and np.array_equal(rm, mask)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "refdim"])
+def test_bimodal_oracle_matches_reference_class(golden_dir, tag):
+    """oracle/bimodal_oracle.py vs the outputs of the reference's own TransformerNoduleBimodalClassifier
+    (models_archs.py:38-124; tests/golden/make_golden_bimodal.py), all three modality modes, <= 2e-5."""
+    from oracle import bimodal_oracle as bo
+    g = np.load(os.path.join(golden_dir, f"bimodal_{tag}.npz"), allow_pickle=False)
+    dim, lc, lp = int(g["dim"]), int(g["layers_ct"]), int(g["layers_pet"])
+    fc, fp = int(float(g["ratio_ct"]) * dim), int(float(g["ratio_pet"]) * dim)
+    sd = bo.make_state_dict(dim, fc, fp, lc, lp, int(g["classes"]), seed=int(g["seed"]))
+    assert np.array_equal(sd["cross_attention_ct.multihead_attn.in_proj_weight"][:2, :8].numpy(), g["w_probe"])
+    x_ct, x_pet = torch.from_numpy(g["x_ct"]), torch.from_numpy(g["x_pet"])
+    for mode, (a, b) in (("both", (x_ct, x_pet)), ("ct", (x_ct, None)), ("pet", (None, x_pet))):
+        out = bo.forward(sd, dim, fc, fp, int(g["heads_ct"]), int(g["heads_pet"]), lc, lp, a, b)
+        for name, o in zip(("logits_petct", "cls_petct", "logits_ct", "logits_pet"), out):
+            want = torch.from_numpy(g[f"{mode}_{name}"])
+            assert o.shape == want.shape and (o - want).abs().max().item() < 2e-5, (mode, name)

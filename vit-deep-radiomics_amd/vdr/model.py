@@ -179,3 +179,110 @@ class TransformerNoduleClassifier:
         hid = ops.linear(cls.to(torch.bfloat16), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
         logits = ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.num_classes].float()
         return logits, cls
+
+
+class _MlpHead:
+    """models_archs.MLPLayer (:186-200) in eval mode through vdr_op_linear; dense2's rows zero-padded to a multiple
+    of 8 (the GEMM's N rule)."""
+
+    def __init__(self, sd, prefix, dev):
+        self.w1 = sd[prefix + ".dense1.weight"].to(dev, torch.bfloat16).contiguous()
+        self.b1 = sd[prefix + ".dense1.bias"].to(dev, torch.float32).contiguous()
+        w2, b2 = sd[prefix + ".dense2.weight"].float().cpu(), sd[prefix + ".dense2.bias"].float().cpu()
+        self.n = w2.shape[0]
+        npad = (self.n + 7) // 8 * 8
+        wp = torch.zeros((npad, w2.shape[1]), dtype=torch.float32)
+        wp[: self.n] = w2
+        bp = torch.zeros((npad,), dtype=torch.float32)
+        bp[: self.n] = b2
+        self.w2, self.b2 = wp.to(dev, torch.bfloat16).contiguous(), bp.to(dev)
+
+    def __call__(self, x):
+        from . import ops
+        hid = ops.linear(x.to(torch.bfloat16).contiguous(), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
+        return ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.n].float()
+
+
+class _CrossAttentionCls:
+    """CrossAttentionLayer (models_archs.py:174-183 = nn.MultiheadAttention, batch_first, no key padding mask) of
+    which the bimodal forward consumes only the CLS query row (`x_attn[:, 0, :]`, :101-102).  Runs on the
+    self-attention kernel: keys / values of the other modality are projected into the k | v columns of a packed
+    [B*S, 3D] activation whose q columns hold the projected CLS query in row 0 of every sequence; row 0 of the
+    kernel's output is then exactly softmax(q_cls K^T / sqrt(dh)) V."""
+
+    def __init__(self, sd, prefix, heads, dev):
+        W = sd[prefix + ".multihead_attn.in_proj_weight"].float()
+        b = sd[prefix + ".multihead_attn.in_proj_bias"].float()
+        D = W.shape[1]
+        if D != heads * 64:
+            raise ValueError(f"cross attention needs head dim 64 (dim {D}, heads {heads})")
+        self.D, self.heads = D, heads
+        self.wq, self.bq = W[:D].to(dev, torch.bfloat16).contiguous(), b[:D].to(dev).contiguous()
+        self.wkv, self.bkv = W[D:].to(dev, torch.bfloat16).contiguous(), b[D:].to(dev).contiguous()
+        self.wo = sd[prefix + ".multihead_attn.out_proj.weight"].to(dev, torch.bfloat16).contiguous()
+        self.bo = sd[prefix + ".multihead_attn.out_proj.bias"].to(dev, torch.float32).contiguous()
+
+    def __call__(self, xq, xkv):
+        """xq [B, Sq, D], xkv [B, Sk, D] bf16 token sequences -> [B, D] fp32 (row 0 of the attention output)."""
+        from . import ops
+        B, Sk, D = xkv.shape
+        q = ops.linear(xq[:, 0, :].contiguous(), self.wq, self.bq)                      # [B, D]
+        qkv = torch.zeros((B, Sk, 3 * D), dtype=torch.bfloat16, device=xkv.device)
+        qkv[:, :, D:] = ops.linear(xkv.reshape(B * Sk, D).contiguous(), self.wkv, self.bkv).view(B, Sk, 2 * D)
+        qkv[:, 0, :D] = q
+        o = ops.attention(qkv.view(B * Sk, 3 * D), B, Sk, self.heads).view(B, Sk, D)[:, 0, :].contiguous()
+        return ops.linear(o, self.wo, self.bo).float()
+
+
+class TransformerNoduleBimodalClassifier:
+    """Drop-in for models_archs.TransformerNoduleBimodalClassifier (:38-124) in eval mode: same constructor
+    arguments plus the state_dict (reference key names), `model(x_ct, x_pet)` ->
+    (logits_petct, petct_cls_token, logits_ct, logits_pet); either modality may be None, as in the reference."""
+
+    def __init__(self, input_dim, mlp_ratio_ct, mlp_ratio_pet, num_heads_ct, num_heads_pet, num_layers_ct, num_layers_pet,
+                 num_classes, state_dict, device=None):
+        from .weights import from_torch_encoder_state_dict
+        sd = state_dict
+        self.engines = {}
+        for m, ratio, heads, layers in (("ct", mlp_ratio_ct, num_heads_ct, num_layers_ct),
+                                        ("pet", mlp_ratio_pet, num_heads_pet, num_layers_pet)):
+            cfg = VdrConfig(img=0, patch=0, in_chans=0, dim=input_dim, heads=heads, layers=layers,
+                            mlp_hidden=int(ratio * input_dim), act="gelu", pre_ln=False, layerscale=False, has_cls=True,
+                            has_pos=False, input_ln=True, ln_eps=1e-5)
+            eng = Engine(cfg, device)
+            sub = {"cls_token": sd[f"cls_token_{m}"], "norm.weight": sd[f"norm_{m}.weight"], "norm.bias": sd[f"norm_{m}.bias"]}
+            pre = f"transformer_encoder_{m}."
+            sub.update({"transformer_encoder." + k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+            eng.load_weights(from_torch_encoder_state_dict(sub, layers))
+            self.engines[m] = eng
+        dev = self.engines["ct"].device
+        self.device = dev
+        self.num_classes = num_classes
+        # the reference constructs BOTH cross-attention layers with num_heads_ct (:71-72)
+        self.cross = {m: _CrossAttentionCls(sd, f"cross_attention_{m}", num_heads_ct, dev) for m in ("ct", "pet")}
+        self.heads = {n: _MlpHead(sd, n, dev) for n in ("classifier_ct", "classifier_pet", "projection_petct", "classifier_petct")}
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, x_ct=None, x_pet=None):
+        if x_ct is None and x_pet is None:
+            raise AssertionError("At least one modality should be used")  # the reference's assert
+        t = {}
+        for m, x in (("ct", x_ct), ("pet", x_pet)):
+            if x is not None:
+                mode = L.OUT_TOKENS if (x_ct is not None and x_pet is not None) else L.OUT_CLS
+                t[m] = self.engines[m].forward_tokens(x, mode, torch.bfloat16 if mode == L.OUT_TOKENS else torch.float32)
+        if len(t) == 2:
+            ct_cls = self.cross["ct"](t["ct"], t["pet"])
+            pet_cls = self.cross["pet"](t["pet"], t["ct"])
+            logits_ct, logits_pet = self.heads["classifier_ct"](ct_cls), self.heads["classifier_pet"](pet_cls)
+            fused = self.heads["projection_petct"](torch.cat([ct_cls, pet_cls], dim=1))
+            return self.heads["classifier_petct"](fused), fused, logits_ct, logits_pet
+        m = "ct" if "ct" in t else "pet"
+        cls = t[m]
+        lg = self.heads["classifier_" + m](cls)
+        return lg, cls, lg, lg
