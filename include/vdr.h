@@ -255,6 +255,14 @@ int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C
 size_t vdr_affine_cubic_scratch_bytes(int h, int w, int64_t planes);
 int vdr_op_affine_cubic(const void* src, int dtype, int h, int w, int64_t planes, const double* matrix,
                         const double* offset, void* out, int clip01, void* scratch, void* stream);
+/* Stage-C input sequence (train_models.py:143-182 'transformer' branch + positional_encoding_3d :30-44):
+ * out[r, :] = feat[index[r], :] + PE(x_r, y_r, z_r) / 4, the masked voxels of an (h, w, S) feature volume with their
+ * 3-D sinusoidal position code.
+ *   feat   fp32 [positions, D], positions in (h, w, S) order;  index int64 [n] positions kept (ascending)
+ *   xyz    fp64 [3][n] coordinates of the kept voxels;  expo fp64 [D / 6] = scale^(6 i / D)
+ *   out    [n, D] fp32 (VDR_F32), bf16 (VDR_BF16) or fp64 (VDR_F64, what numpy produces) */
+int vdr_op_voxel_sequence(const float* feat, const int64_t* index, const double* xyz, const double* expo, int64_t n,
+                          int D, void* out, int out_dtype, void* stream);
 
 /* F.scaled_dot_product_attention over a packed qkv activation — the core of
  * nn.MultiheadAttention (models_archs.py:130) / Attention.forward of the ViTs.

@@ -141,3 +141,50 @@ def prepare_image(img, side=None):
         x = img
         side = side or 896
     return resize_hwc(x, side, side).transpose(2, 0, 1)
+
+
+# ---- Stage-C input builder: train_models.py:30-44 (positional_encoding_3d) and :143-182 (_get_features) ------------
+def resize_mask_nearest(mask, out_hw):
+    """skimage.transform.resize(mask, out_hw, order=0) of a boolean mask: nearest sample of the pixel-centre
+    mapping x = (o + 0.5) * in / out - 0.5 (pinned by skimage 0.18.3 values, tests/golden/sequence_cases.npz)."""
+    mask = np.asarray(mask)
+    H, W = mask.shape
+    oh, ow = out_hw
+    yi = np.clip(np.floor((np.arange(oh) + 0.5) * H / oh - 0.5 + 0.5).astype(np.int64), 0, H - 1)
+    xi = np.clip(np.floor((np.arange(ow) + 0.5) * W / ow - 0.5 + 0.5).astype(np.int64), 0, W - 1)
+    return mask[yi][:, xi].astype(bool)
+
+
+def positional_encoding_3d(x, y, z, D, scale=10000):
+    x, y, z = np.asarray(x), np.asarray(y), np.asarray(z)
+    enc = np.zeros((x.shape[0], D))
+    for i in range(D // 6):
+        e = scale ** (6 * i / D)
+        for off, v in ((0, x), (D // 3, y), (2 * D // 3, z)):
+            enc[:, 2 * i + off] = np.sin(v / e)
+            enc[:, 2 * i + 1 + off] = np.cos(v / e)
+    return enc
+
+
+def voxel_coordinates(h, w, S, orig_hw, spatial_res, noise):
+    """(x, y, z) float64 [h*w*S] of every flat position of the (h, w, S) feature volume, exactly as :162-173 computes
+    them: np.meshgrid's default 'xy' indexing returns (w, h, S)-shaped grids that the reference flattens against the
+    (h, w, S)-ordered features, so for non-square maps x / y follow that flat order, not the voxel's own row / column
+    (consumers were trained on it)."""
+    x, y, z = np.meshgrid(np.arange(0, h), np.arange(0, w), np.arange(0, S))
+    x = (x.flatten() / w).flatten() * orig_hw[1] * spatial_res[0]
+    y = (y.flatten() / h).flatten() * orig_hw[0] * spatial_res[1]
+    z = (z.flatten()).flatten() * spatial_res[2]
+    return x - x.mean() + noise[0], y - y.mean() + noise[1], z - z.mean() + noise[2]
+
+
+def masked_voxel_sequence(slice_features, slice_masks, spatial_res, noise=(0.0, 0.0, 0.0)):
+    """The 'transformer' branch of _get_features: (seq [n, D] float64, keep [h*w*S] bool)."""
+    feats = np.stack([np.asarray(f) for f in slice_features], axis=0)               # (S, h, w, D)
+    S, h, w, D = feats.shape
+    masks = np.stack([resize_mask_nearest(m, (h, w)) for m in slice_masks], axis=0)  # (S, h, w)
+    keep = np.transpose(masks, (1, 2, 0)).reshape(-1)
+    vol = np.transpose(feats, (1, 2, 0, 3)).reshape(-1, D)
+    x, y, z = voxel_coordinates(h, w, S, np.asarray(slice_masks[-1]).shape[0:2], spatial_res, noise)
+    pe = positional_encoding_3d(x[keep], y[keep], z[keep], D)
+    return vol[keep, :] + pe / 4, keep

@@ -203,3 +203,22 @@ def test_bimodal_oracle_matches_reference_class(golden_dir, tag):
         for name, o in zip(("logits_petct", "cls_petct", "logits_ct", "logits_pet"), out):
             want = torch.from_numpy(g[f"{mode}_{name}"])
             assert o.shape == want.shape and (o - want).abs().max().item() < 2e-5, (mode, name)
+
+
+def test_voxel_sequence_oracle_matches_goldens_and_zoom(golden_dir):
+    """Stage-C input builder (train_models.py:30-44, :143-182): the oracle reproduces the fixtures made with the
+    reference's numpy / skimage calls exactly (kept voxels, float64 sequences); its nearest mask resize equals
+    scipy.ndimage.zoom(order=0, grid_mode=True) — what current skimage calls — also where samples fall on ties."""
+    from scipy import ndimage as ndi
+    from oracle import prep_oracle as po
+    g = np.load(os.path.join(golden_dir, "sequence_cases.npz"))
+    for n in g["names"]:
+        seq, keep = po.masked_voxel_sequence(list(g[f"{n}_feats"]), list(g[f"{n}_masks"]), g[f"{n}_res"], g[f"{n}_noise"])
+        assert np.array_equal(keep, g[f"{n}_keep"]) and seq.dtype == np.float64
+        assert np.array_equal(seq, g[f"{n}_seq"]), n
+    rng = np.random.default_rng(0)
+    for H, W, h, w in ((40, 40, 12, 12), (64, 64, 10, 10), (64, 64, 16, 16), (33, 51, 9, 14), (11, 9, 20, 18), (30, 50, 15, 25)):
+        m = rng.random((H, W)) > 0.5
+        assert np.array_equal(po.resize_mask_nearest(m, (h, w)), ndi.zoom(m, (h / H, w / W), order=0, mode="mirror", grid_mode=True))
+    pe = po.positional_encoding_3d([1.0], [2.0], [3.0], 50)   # D % 3 == 2: the z block starts at (2 D) // 3 = 33
+    assert pe[0, 16] == np.sin(2.0) and pe[0, 33] == np.sin(3.0) and pe[0, 32] == 0.0

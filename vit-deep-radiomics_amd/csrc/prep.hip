@@ -294,4 +294,39 @@ hipError_t launch_crop_hwc(const float* src, float* dst, int batch, int H, int W
   return hipGetLastError();
 }
 
+// Stage-C input builder (reference src/train_models.py:143-182, 'transformer' branch of _get_features, with
+// positional_encoding_3d :30-44): out[r, :] = feat[index[r], :] + PE(x_r, y_r, z_r) / 4 for the kept (masked) voxels.
+// PE: for i < D / 6, e_i = scale^(6 i / D): columns (2i, 2i + 1) + {0, D/3, 2D/3} = (sin, cos)(coordinate / e_i); every
+// other column 0.  float64 like numpy (the sum is rounded once to the output type); the exponents come from the host
+// (numpy evaluates scale ** (6 * i / D) with libm's pow).
+template <typename TOUT>
+__global__ __launch_bounds__(256) void voxel_sequence_kernel(const float* __restrict__ feat, const int64_t* __restrict__ index,
+                                                              const double* __restrict__ xyz, const double* __restrict__ expo,
+                                                              int64_t n, int D, TOUT* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * D) return;
+  const int64_t r = i / D;
+  const int c = (int)(i % D);
+  const int yoff = D / 3, zoff = (2 * D) / 3, nf = D / 6;  // the reference writes `2 * D // 3` = (2 D) // 3
+  const int axis = c >= zoff ? 2 : c >= yoff ? 1 : 0;
+  const int k = c - (axis == 2 ? zoff : axis == 1 ? yoff : 0);
+  double pe = 0.0;
+  if (k < 2 * nf) {  // 2 (D / 6) <= D / 3: the three blocks never overlap, the columns between them stay 0
+    const double v = xyz[(int64_t)axis * n + r] / expo[k >> 1];
+    pe = (k & 1) ? cos(v) : sin(v);
+  }
+  const double sum = (double)feat[index[r] * D + c] + pe / 4;
+  out[i] = (TOUT)sum;
+}
+
+hipError_t launch_voxel_sequence(const float* feat, const int64_t* index, const double* xyz, const double* expo, int64_t n,
+                                 int D, void* out, int out_dtype /*0 f32, 1 bf16, 2 f64*/, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const unsigned g = (unsigned)((n * D + 255) / 256);
+  if (out_dtype == 0) hipLaunchKernelGGL(voxel_sequence_kernel<float>, dim3(g), dim3(256), 0, s, feat, index, xyz, expo, n, D, (float*)out);
+  else if (out_dtype == 1) hipLaunchKernelGGL(voxel_sequence_kernel<bf16_t>, dim3(g), dim3(256), 0, s, feat, index, xyz, expo, n, D, (bf16_t*)out);
+  else hipLaunchKernelGGL(voxel_sequence_kernel<double>, dim3(g), dim3(256), 0, s, feat, index, xyz, expo, n, D, (double*)out);
+  return hipGetLastError();
+}
+
 }  // namespace vdr

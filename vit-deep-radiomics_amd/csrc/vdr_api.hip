@@ -1373,6 +1373,19 @@ int vdr_op_crop_hwc(const float* src, float* dst, int batch, int H, int W, int C
   return VDR_OK;
 }
 
+int vdr_op_voxel_sequence(const float* feat, const int64_t* index, const double* xyz, const double* expo, int64_t n, int D,
+                          void* out, int out_dtype, void* stream) {
+  if (n < 0 || D < 6) return fail(nullptr, VDR_ERR_INVALID, "voxel_sequence: n >= 0, D >= 6");
+  if (n == 0) return VDR_OK;
+  if (!feat || !index || !xyz || !expo || !out) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  const int dt = out_dtype == VDR_F32 ? 0 : out_dtype == VDR_BF16 ? 1 : out_dtype == VDR_F64 ? 2 : -1;
+  if (dt < 0) return fail(nullptr, VDR_ERR_UNSUPPORTED, "voxel_sequence: fp32, bf16 or fp64 output");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_voxel_sequence(feat, index, xyz, expo, n, D, out, dt, (hipStream_t)stream), "voxel_sequence");
+  return VDR_OK;
+}
+
 size_t vdr_affine_cubic_scratch_bytes(int h, int w, int64_t planes) {
   if (h <= 0 || w <= 0 || planes <= 0) return 0;
   return affine_cubic_scratch_bytes(h, w, planes);

@@ -106,6 +106,8 @@ hipError_t launch_crop_hwc(const float* src, float* dst, int batch, int H, int W
                            hipStream_t s);
 // scipy.ndimage.affine_transform(order=3, mode='nearest', prefilter=True) on every (H, W) plane of an [H, W, planes]
 // volume (rotate.hip); dtype 0 f64, 1 f32, 2 u8 (boolean mask, truncating store); scratch = affine_cubic_scratch_bytes
+hipError_t launch_voxel_sequence(const float* feat, const int64_t* index, const double* xyz, const double* expo, int64_t n,
+                                 int D, void* out, int out_dtype, hipStream_t s);
 size_t affine_cubic_scratch_bytes(int H, int W, int64_t planes);
 hipError_t launch_affine_cubic(const void* src, int dtype, int H, int W, int64_t planes, const double* matrix,
                                const double* offset, void* out, int clip01, double* scratch, hipStream_t s);

@@ -52,6 +52,7 @@ SYMBOLS = {
     "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),
     "vdr_op_hu_to_rgb": (_I, [_P, _I, _L, _P, _P]),
     "vdr_op_crop_hwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vdr_op_voxel_sequence": (_I, [_P, _P, _P, _P, _L, _I, _P, _I, _P]),
     "vdr_affine_cubic_scratch_bytes": (C.c_size_t, [_I, _I, _L]),
     "vdr_op_affine_cubic": (_I, [_P, _I, _I, _I, _L, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _I, _P, _P]),
     "vdr_mx_scale_bytes": (C.c_size_t, [_L, _I]),

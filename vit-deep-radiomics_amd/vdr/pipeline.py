@@ -219,3 +219,56 @@ def extract_patient_features(model, img_raw, mask_raw, patient_id, label, datase
 
 def save_metadata(df, df_path):
     df.to_parquet(df_path)
+
+
+# ---- train_models.py:30-44, :143-182 --------------------------------------------------------------------------
+def resize_mask_nearest(mask, out_hw):
+    """skimage.transform.resize(mask, out_hw, order=0) of a boolean mask (nearest sample of the pixel-centre
+    mapping, = scipy.ndimage.zoom(order=0, grid_mode=True), what current skimage calls)."""
+    mask = np.asarray(mask)
+    H, W = mask.shape
+    oh, ow = out_hw
+    yi = np.clip(np.floor((np.arange(oh) + 0.5) * H / oh - 0.5 + 0.5).astype(np.int64), 0, H - 1)
+    xi = np.clip(np.floor((np.arange(ow) + 0.5) * W / ow - 0.5 + 0.5).astype(np.int64), 0, W - 1)
+    return mask[yi][:, xi].astype(bool)
+
+
+def masked_voxel_sequence(slice_features, slice_masks, spatial_res, noise=(0.0, 0.0, 0.0), out_dtype=torch.float32,
+                          device=None):
+    """The Stage-C input of one patient and modality, as the 'transformer' branch of PETCTDataset3D._get_features
+    builds it (train_models.py:143-182): per-slice (h, w, D) feature maps + nodule masks -> [n, D] sequence of the
+    masked voxels, each with its 3-D sinusoidal position code / 4 added (positional_encoding_3d, :30-44).
+
+    Host side (integer / small float64 logic, restated): nearest mask resize, kept-voxel indices, coordinates — with
+    the reference's np.meshgrid 'xy' flat order, mean-centring and `noise` offsets.  Device side
+    (vdr_op_voxel_sequence): gather + sin / cos + add, float64 like numpy, rounded once to `out_dtype`.
+    slice_features may be numpy arrays (uploaded once) or one device tensor [S, h, w, D]."""
+    lib = L.load()
+    if isinstance(slice_features, torch.Tensor):
+        feats = slice_features
+    else:
+        feats = torch.from_numpy(np.stack([np.asarray(f, dtype=np.float32) for f in slice_features], axis=0))
+    dev = device if device is not None else (feats.device if feats.is_cuda else "cuda")
+    S, h, w, D = feats.shape
+    vol = feats.to(dev, torch.float32).permute(1, 2, 0, 3).contiguous().view(-1, D)       # (h, w, S) positions
+    masks = np.stack([resize_mask_nearest(m, (h, w)) for m in slice_masks], axis=0)
+    keep = np.transpose(masks, (1, 2, 0)).reshape(-1)
+    h0, w0 = np.asarray(slice_masks[-1]).shape[0:2]
+    x, y, z = np.meshgrid(np.arange(0, h), np.arange(0, w), np.arange(0, S))              # 'xy' indexing, as the reference
+    x = (x.flatten() / w).flatten() * w0 * spatial_res[0]
+    y = (y.flatten() / h).flatten() * h0 * spatial_res[1]
+    z = (z.flatten()).flatten() * spatial_res[2]
+    xyz = np.stack([(x - x.mean() + noise[0])[keep], (y - y.mean() + noise[1])[keep], (z - z.mean() + noise[2])[keep]])
+    index = np.flatnonzero(keep).astype(np.int64)
+    n = int(index.shape[0])
+    out = torch.empty((n, D), dtype=out_dtype, device=vol.device)
+    if n == 0:
+        return out
+    expo = np.array([10000 ** (6 * i / D) for i in range(D // 6)], dtype=np.float64)
+    d_index = torch.from_numpy(index).to(vol.device)
+    d_xyz = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float64)).to(vol.device)
+    d_expo = torch.from_numpy(expo).to(vol.device)
+    odt = {torch.float32: L.VDR_F32, torch.bfloat16: L.VDR_BF16, torch.float64: L.VDR_F64}[out_dtype]
+    L.check(lib.vdr_op_voxel_sequence(vol.data_ptr(), d_index.data_ptr(), d_xyz.data_ptr(), d_expo.data_ptr(), n, D,
+                                      out.data_ptr(), odt, torch.cuda.current_stream(vol.device).cuda_stream))
+    return out
