@@ -308,6 +308,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 2 
 }
 
 
+template <int EPI, int TM, int TN>
+VDR_DEV void epilogue_direct(const GemmK& p, f32x16 (&acc)[TN][TM], int64_t m_base, int n_base, int lane);  // defined below
+
 // -------------------------------------------------------------------------------------------------
 // Ring variant 2: the barrier of a step sits in the MIDDLE of its MFMAs.
 //   top of step s :  X holds the k-step-0 fragments of unit s (read during step s-1)
