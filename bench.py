@@ -122,6 +122,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
 
+    # a checkout without the built library (artefacts are git-ignored): build it once, rank 0 first, exactly as
+    # __graft_entry__.build() does; the product itself never builds or falls back (vdr.load() raises without the .so)
+    lib_path = os.path.join(ROOT, "vit-deep-radiomics_amd", "vdr", "libvdr.so")
+    if not os.path.exists(lib_path):
+        if rank == 0:
+            import subprocess
+            subprocess.run(["make", "-C", os.path.join(ROOT, "vit-deep-radiomics_amd", "csrc"), "-j8"], check=True,
+                           stdout=subprocess.DEVNULL)
+        if launched:
+            dist.barrier()
     import vdr
     from vdr.dist import all_gather_rows
     from oracle import vit_oracle as vo  # weights/images generators + cpu_baseline only
