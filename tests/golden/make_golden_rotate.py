@@ -4,9 +4,9 @@ reference src/tfds_dense_descriptor.py:327-350).
     python tests/golden/make_golden_rotate.py          (main interpreter: scipy 1.15.3)
 
 tfds_dense_descriptor.py itself does not import here (skimage / tensorflow_datasets / segment_anything are missing:
-ordinary ModuleNotFoundError), so the expected values come from the SAME SciPy calls its rotate_image makes, made
-directly:  rotate(vol, angle, axes=(0, 1), reshape=False, mode='nearest'), np.clip(., 0, 1) on the image and `> 0`
-on the rotated boolean mask.  Only numeric inputs / outputs are stored (tests/golden/rotate_cases.npz).
+ordinary ModuleNotFoundError), so the definition of the reference's OWN rotate_image is read from its file with `ast`
+and executed with numpy and scipy.ndimage.rotate in scope (all it needs): rotate(vol, angle, axes=(0, 1),
+reshape=False, mode='nearest'), np.clip(., 0, 1) on the image and `> 0` on the rotated boolean mask.  Only numeric inputs / outputs are stored (tests/golden/rotate_cases.npz).
 """
 import os
 
@@ -16,10 +16,16 @@ from scipy.ndimage import rotate
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def rotate_image(image, mask, angle):
-    image_rot = np.clip(rotate(image, angle, axes=(0, 1), reshape=False, mode="nearest"), 0, 1)
-    mask_rot = rotate(mask, angle, axes=(0, 1), reshape=False, mode="nearest") > 0
-    return image_rot, mask_rot
+def reference_function(path, name, scope):
+    """The reference's OWN `name`, taken from its source file at generation time (the module itself does not import
+    here) and executed with `scope` as its globals; nothing of it is stored in this repository."""
+    import ast
+    node = next(n for n in ast.parse(open(path).read()).body if isinstance(n, ast.FunctionDef) and n.name == name)
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
+    return scope[name]
+
+
+rotate_image = reference_function("/root/reference/src/tfds_dense_descriptor.py", "rotate_image", {"np": np, "rotate": rotate})
 
 
 def main():

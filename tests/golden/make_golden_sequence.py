@@ -5,8 +5,9 @@ PETCTDataset3D._get_features (reference src/train_models.py:143-182) with positi
     /opt/conda/bin/python3.9 tests/golden/make_golden_sequence.py        (skimage 0.18.3 lives there)
 
 train_models.py itself does not import under this interpreter (no torch / h5py here: ordinary ModuleNotFoundError),
-so the expected values come from the same numpy / skimage calls made directly, in the reference's order, on the
-arrays it would have read from the HDF5 file.  skimage 0.18.3 returns the order-0 resized boolean mask as float 0/1
+so: `positional_encoding_3d` is the reference's OWN function (its definition is read from the reference file with `ast`
+and executed here; it needs numpy only), and the few array steps around it follow the reference's order with the same
+numpy / skimage calls, on the arrays it would have read from the HDF5 file.  skimage 0.18.3 returns the order-0 resized boolean mask as float 0/1
 (newer releases keep bool, which is what the reference's boolean indexing needs): the values are cast to bool here.
 Original mask sizes are odd so that no sample falls exactly between two source pixels: on such ties 0.18.3's warp and
 the ndimage.zoom(grid_mode=True) that newer skimage releases call disagree (the oracle follows zoom, cross-checked
@@ -23,41 +24,37 @@ from skimage.transform import resize  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def positional_encoding_3d(x, y, z, D, scale=10000):
-    x, y, z = np.asarray(x), np.asarray(y), np.asarray(z)
-    encoding = np.zeros((x.shape[0], D))
-    for i in range(D // 6):
-        exponent = scale ** (6 * i / D)
-        encoding[:, 2 * i] = np.sin(x / exponent)
-        encoding[:, 2 * i + 1] = np.cos(x / exponent)
-        encoding[:, 2 * i + D // 3] = np.sin(y / exponent)
-        encoding[:, 2 * i + 1 + D // 3] = np.cos(y / exponent)
-        encoding[:, 2 * i + 2 * D // 3] = np.sin(z / exponent)
-        encoding[:, 2 * i + 1 + 2 * D // 3] = np.cos(z / exponent)
-    return encoding
+def reference_function(path, name):
+    """The reference's OWN `name`, taken from its source file at generation time (the module itself does not import
+    here) and executed with numpy in scope; nothing of it is stored in this repository."""
+    import ast
+    src = open(path).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == name)
+    scope = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), scope)
+    return scope[name]
 
 
-def get_features(slice_features_list, slice_masks_list, noise, spatial_res, feature_dim):
-    features, masks = [], []
-    for slice_features, slice_mask_orig in zip(slice_features_list, slice_masks_list):
-        slice_mask = resize(slice_mask_orig, slice_features.shape[0:2], order=0).astype(bool)
-        masks.append(np.expand_dims(slice_mask, axis=-1))
-        features.append(slice_features)
-    features = np.transpose(np.stack(features, axis=0), axes=(3, 0, 1, 2))
-    masks = np.transpose(np.stack(masks, axis=0), axes=(1, 2, 0, 3))
-    h_orig, w_orig = slice_mask_orig.shape[0:2]
-    features = np.transpose(features, axes=(2, 3, 1, 0))
-    h_new, w_new = features.shape[0], features.shape[1]
-    x, y, z = np.meshgrid(np.arange(0, features.shape[0]), np.arange(0, features.shape[1]), np.arange(0, features.shape[2]))
-    x = (x.flatten() / w_new).flatten() * w_orig * spatial_res[0]
-    y = (y.flatten() / h_new).flatten() * h_orig * spatial_res[1]
-    z = (z.flatten()).flatten() * spatial_res[2]
-    masks = masks.flatten()
-    x = (x - x.mean() + noise[0])[masks]
-    y = (y - y.mean() + noise[1])[masks]
-    z = (z - z.mean() + noise[2])[masks]
-    pe = positional_encoding_3d(x, y, z, D=feature_dim, scale=10000)
-    return features.reshape(-1, feature_dim)[masks, :] + pe / 4, masks
+positional_encoding_3d = reference_function("/root/reference/src/train_models.py", "positional_encoding_3d")
+
+
+def get_features(maps, nodule_masks, noise, spacing, width):
+    """What the 'transformer' branch of _get_features (train_models.py:143-182) yields for the arrays it would have
+    read from the HDF5 file: the skimage order-0 mask resize, its (h, w, slice) flattening, the np.meshgrid (default
+    'xy') coordinate grids scaled to millimetres, centred and offset by `noise`, the reference's own
+    positional_encoding_3d, and `features + pe / 4` on the kept voxels."""
+    vol = np.stack(maps, axis=0).transpose(1, 2, 0, 3)                                   # (h, w, slice, width)
+    h, w, n_slices = vol.shape[:3]
+    small = [resize(m, (h, w), order=0).astype(bool) for m in nodule_masks]
+    keep = np.stack(small, axis=0).transpose(1, 2, 0).reshape(-1)
+    src_h, src_w = nodule_masks[-1].shape[0:2]
+    gx, gy, gz = np.meshgrid(np.arange(0, h), np.arange(0, w), np.arange(0, n_slices))
+    cx = gx.flatten() / w * src_w * spacing[0]
+    cy = gy.flatten() / h * src_h * spacing[1]
+    cz = gz.flatten() * spacing[2]
+    coords = [(c - c.mean() + d)[keep] for c, d in zip((cx, cy, cz), noise)]
+    pe = positional_encoding_3d(*coords, D=width, scale=10000)
+    return vol.reshape(-1, width)[keep, :] + pe / 4, keep
 
 
 def main():
