@@ -10,7 +10,8 @@ What produces the expected values:
   * prepare_image's numpy part (tfds_dense_descriptor.py:43-47: gray2rgb + skimage.transform.resize): the
     same skimage calls made directly, because tfds_dense_descriptor.py itself needs torch / tensorflow_datasets
     / segment_anything, which this interpreter does not have (ordinary ModuleNotFoundError);
-  * apply_window_ct (tfds_dense_descriptor.py:287-302): the two-line formula evaluated with numpy here.
+  * apply_window_ct / windowing_ct (tfds_dense_descriptor.py:204-237, 287-302): the reference's OWN functions, their
+    definitions read from the reference file with `ast` and executed with numpy in scope.
 Only numeric inputs / outputs are stored (tests/golden/prep_*.npz).
 """
 import os
@@ -99,10 +100,17 @@ def gen_window():
     ct = rng.integers(-1200, 1200, (24, 24)).astype(np.int16)
     ctf = rng.uniform(-1200, 1200, (24, 24)).astype(np.float32)
     out = {"ct_i16": ct, "ct_f32": ctf}
+    # the reference's OWN apply_window_ct / windowing_ct: their definitions are read from the reference file and executed
+    # with numpy in scope (the module itself needs torch / tensorflow_datasets / segment_anything to import)
+    import ast
+    path = "/root/reference/src/tfds_dense_descriptor.py"
+    scope = {"np": np}
+    body = [n for n in ast.parse(open(path).read()).body
+            if isinstance(n, ast.FunctionDef) and n.name in ("windowing_ct", "apply_window_ct")]
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), scope)
     for tag, (w, l) in {"w800_l40": (800, 40), "w1500_lm600": (1500, -600), "w350_l50": (350, 50)}.items():
-        lo, hi = l - w / 2, l + w / 2                                  # windowing_ct (:204-237)
         for nm, a in (("i16", ct), ("f32", ctf)):
-            out[f"{tag}_{nm}"] = np.clip((a - lo) / (hi - lo), 0, 1)  # apply_window_ct (:287-302)
+            out[f"{tag}_{nm}"] = scope["apply_window_ct"](a, width=w, level=l)
     np.savez_compressed(os.path.join(HERE, "prep_window.npz"), **out)
 
 
