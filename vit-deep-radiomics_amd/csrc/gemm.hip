@@ -20,7 +20,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
   g_gemm_ablation = variant / 100;
   variant %= 100;
-  if ((a.ln_stats || a.ln_part || a.win_ws || a.a_rpg || a.out_f32) && variant < 12) return hipErrorInvalidValue;
+  if ((a.ln_stats || a.ln_cpart || a.ln_part || a.win_ws || a.a_rpg || a.out_f32) && variant < 12) return hipErrorInvalidValue;
   if (a.out_f32 && epilogue != EPI_BIAS) return hipErrorInvalidValue;  // needs epilogue_lds (ring2 / ring3)
   if (a.ln_part && (a.N & 63)) return hipErrorInvalidValue;
   if (variant < 12) return launch_gemm_legacy(a, epilogue, variant, s);

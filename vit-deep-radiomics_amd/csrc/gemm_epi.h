@@ -28,6 +28,15 @@ struct GemmK {
   int64_t m_split;  // ring2: first row covered by half-height tiles
   const float* ln_stats;
   const float* colsum;
+  // LayerNorm fold with the (mean, rstd) finalisation inside the GEMM (ring3 kernels): the producers' (sum, sumsq)
+  // partials [ln_groups][ln_cstride][2]; every workgroup turns those of its BM rows into (mean, rstd) in LDS at
+  // stats_off while its ring fills (same arithmetic as ln_finalize_kernel: double, groups in order)
+  const float* ln_cpart = nullptr;
+  int ln_groups = 0;
+  int64_t ln_cstride = 0;
+  float ln_inv_d = 0.0f, ln_eps = 0.0f;
+  int stats_off = 0;
+  int ln_fold = 0;  // the consumer-side fold is on (statistics from ln_stats or from ln_cpart)
   float* ln_part;
   int64_t part_stride;
   int a_rpg;
@@ -131,7 +140,7 @@ VDR_DEV EpiCols load_epi_cols(const GemmK& p, int n) {
     e.b0 = *reinterpret_cast<const f32x4*>(p.bias + nn);
     e.b1 = *reinterpret_cast<const f32x4*>(p.bias + nn + 4);
   }
-  if (p.ln_stats) {
+  if (p.ln_fold) {
     e.c0 = *reinterpret_cast<const f32x4*>(p.colsum + nn);
     e.c1 = *reinterpret_cast<const f32x4*>(p.colsum + nn + 4);
   }
@@ -174,7 +183,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     if (y >= g || x >= g) return -1;  // zero padding of the border windows: dropped
     orow = (b * g + y) * g + x;
   }
-  if (p.ln_stats) {
+  if (p.ln_fold) {
     // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
     // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
     f32x4 c0 = ec.c0, c1 = ec.c1;
@@ -363,7 +372,8 @@ VDR_DEV void stage_acc_block(const Acc16& acc, char* stg, int i, int jp, int lan
 }
 
 template <int EPI, int TM, int TN, typename AccT>
-VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane) {
+VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane,
+                          const float2* tile_stats = nullptr) {  // tile_stats: LDS (mean, rstd) of row m_base onwards
   constexpr int E = epi_base(EPI);
   constexpr bool MXO = epi_mx_out(EPI);
   (void)MXO;
@@ -377,7 +387,11 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
     for (int rr = 0; rr < 4; ++rr) {
       st_mu[i][rr] = 0.0f;
       st_rs[i][rr] = 1.0f;
-      if (p.ln_stats) {
+      if (tile_stats) {
+        const float2 t = tile_stats[i * 32 + rr * 8 + (lane >> 3)];
+        st_mu[i][rr] = t.x;
+        st_rs[i][rr] = t.y;
+      } else if (p.ln_stats) {
         int64_t m = m_base + i * 32 + rr * 8 + (lane >> 3);
         m = m < p.M ? m : p.M - 1;
         const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
@@ -444,7 +458,11 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
             u[4 + e] = g1[e];
           }
           float s1, s2, mu = 0.0f, rs = 1.0f;
-          if (p.ln_stats) {
+          if (tile_stats) {
+            const float2 t = tile_stats[i * 32 + row];
+            mu = t.x;
+            rs = t.y;
+          } else if (p.ln_stats) {
             int64_t m = m_base + i * 32 + row;
             m = m < p.M ? m : p.M - 1;
             const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);

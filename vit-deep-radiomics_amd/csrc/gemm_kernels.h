@@ -566,6 +566,22 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
   };
   bf16x8 fb[4], alo[2], ahi[2];
 
+  // LayerNorm fold, statistics in the GEMM: the first BM threads fetch the (sum, sumsq) partials of one row each
+  // BEFORE the ring fill is issued (so the counted vmcnt waits of the ring see them as older operations) and reduce
+  // them after it, while the ring's first units are in flight
+  constexpr int MAXG = 16;
+  float2 pv[MAXG];
+  const bool fold_here = __builtin_amdgcn_readfirstlane(p.ln_cpart != nullptr) && tid < BM;
+  if (fold_here) {
+    int64_t r = m0 + tid;
+    r = r < p.M ? r : p.M - 1;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+      const int gg = g < p.ln_groups ? g : p.ln_groups - 1;
+      pv[g] = *reinterpret_cast<const float2*>(p.ln_cpart + ((int64_t)gg * p.ln_cstride + r) * 2);
+    }
+  }
+
   int issued = -1;
 #pragma unroll
   for (int u = 0; u < NST; ++u)
@@ -573,6 +589,22 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
       stage(u);
       issued = u;
     }
+  if (fold_here) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g)
+      if (g < p.ln_groups) {
+        s1 += (double)pv[g].x;
+        s2 += (double)pv[g].y;
+      }
+    const double mean = s1 * (double)p.ln_inv_d;
+    double var = s2 * (double)p.ln_inv_d - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    float2 o;
+    o.x = (float)mean;
+    o.y = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+    reinterpret_cast<float2*>(smem + p.stats_off)[tid] = o;
+  }
   retire(0, issued);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -616,7 +648,8 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
 
   if (!do_epi && acc.t[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
   __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
-  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane);
+  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane,
+                            p.ln_cpart ? reinterpret_cast<const float2*>(smem + p.stats_off) + wm * 64 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1000,6 +1033,15 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.colsum = a.colsum;
   k.ln_part = a.ln_part;
   k.part_stride = a.part_stride;
+  k.ln_fold = a.ln_stats || a.ln_cpart;
+  if (a.ln_cpart) {
+    if (!(PIPE >= 30 && PIPE < 40) || a.ln_groups < 1 || a.ln_groups > 16 || a.ln_stats) return hipErrorInvalidValue;
+    k.ln_cpart = a.ln_cpart;
+    k.ln_groups = a.ln_groups;
+    k.ln_cstride = a.ln_cstride;
+    k.ln_inv_d = a.ln_inv_d;
+    k.ln_eps = a.ln_eps;
+  }
   k.abl = g_gemm_ablation;
   k.stagger = 0;
   {
@@ -1017,7 +1059,11 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
                                ? (size_t)(BM + BN) * 64 * RING_SLOTS
                                : (size_t)WAVES_M * WAVES_N * 32 * 272;
   const size_t lds_k = lds_ring2 > (size_t)65536 + 4 * 32 * 272 ? lds_ring2 : (size_t)65536 + 4 * 32 * 272;  // ring3k: reduction + staging
-  const size_t lds = PIPE >= 40 ? lds_k : PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
+  size_t lds = PIPE >= 40 ? lds_k : PIPE >= 20 ? lds_ring2 : PIPE >= 10 ? (size_t)(BM + BN) * 64 * (PIPE - 10) : (size_t)(BM + BN) * 128 * (PIPE ? 2 : 1);
+  if (a.ln_cpart) {  // (mean, rstd) of the tile's BM rows, behind the ring / staging area
+    k.stats_off = (int)lds;
+    lds += (size_t)BM * 8;
+  }
 #define VDR_LAUNCH(E)                                                                             \
   case E: {                                                                                       \
     auto fn = launch_pick<WAVES_M, WAVES_N, TM, TN, PIPE, E>();                                   \

@@ -513,7 +513,45 @@ struct LnFold {
   const float* colsum = nullptr;  // consumer: column sums of the folded weight
   float* part = nullptr;          // producer: partial sums out
   int64_t part_stride = 0;
+  const float* cpart = nullptr;   // consumer: the producers' partials, finalised inside the GEMM (instead of stats)
+  int groups = 0;
+  int64_t cstride = 0;
+  float inv_d = 0.0f, eps = 0.0f;
 };
+
+// Where the (sum, sumsq) partials of the residual stream become (mean, rstd): inside the consuming GEMM when it runs
+// a ring3 variant (22-24; every workgroup finalises its own rows in LDS while its ring fills: no launch), otherwise by
+// ln_finalize_kernel ahead of it.  Same arithmetic either way: results are bitwise equal.  Measured (same box,
+// alternating runs): the fetch of the partials adds about a microsecond to every tile's prologue, so it pays where a
+// launch is a handful of tile rounds (MedSAM batch 1: 2.694 -> 2.669 ms, batch 4: 6.606 -> 6.588) and costs where it
+// is many (ViT-B batch 256: qkv +3 %, fc1 +4 % against 0.15 ms of ln_finalize launches: 12.15 -> 12.19 ms): taken
+// for launches of at most 2048 tiles.  VDR_LN_IN_GEMM=0 / 1 forces the separate kernel / the in-GEMM form.
+bool ln_stats_in_gemm(int cls, int64_t M, int N, int groups) {
+  static const int mode = env_int("VDR_LN_IN_GEMM", -1);
+  const int v = gemm_variant_for(cls, M, N);
+  if (mode == 0 || groups > 16 || v < 22 || v > 24) return false;
+  if (mode == 1) return true;
+  return ((M + 127) / 128) * ((N + 255) / 256) <= 2048;
+}
+
+// consumer side of the fold for one GEMM: hands it the partials, or finalises the statistics ahead of it
+int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, const Carve& w, LnFold* cons) {
+  const int groups = D / 64;
+  if (ln_stats_in_gemm(cls, M, N, groups)) {
+    cons->stats = nullptr;
+    cons->cpart = w.part;
+    cons->groups = groups;
+    cons->cstride = w.Mp;
+    cons->inv_d = 1.0f / (float)D;
+    cons->eps = m->cfg.ln_eps;
+    return VDR_OK;
+  }
+  Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
+  VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, m->cfg.ln_eps, s), "ln_finalize");
+  cons->cpart = nullptr;
+  cons->stats = w.stats;
+  return VDR_OK;
+}
 
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold()) {
@@ -522,6 +560,11 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.colsum = ln.colsum;
   g.ln_part = ln.part;
   g.part_stride = ln.part_stride;
+  g.ln_cpart = ln.cpart;
+  g.ln_groups = ln.groups;
+  g.ln_cstride = ln.cstride;
+  g.ln_inv_d = ln.inv_d;
+  g.ln_eps = ln.eps;
   g.A = A;
   g.W = W;
   g.bias = bias;
@@ -650,18 +693,13 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
   if (c.pre_ln && m->ln_fuse) {
     // LayerNorm never materialised: producers leave (sum, sumsq) partials, a tiny kernel turns them into
     // (mean, rstd), the consuming GEMM applies them in its epilogue (weights pre-multiplied by gamma).
-    const int groups = D / 64;
     LnFold prod;
     prod.part = w.part;
     prod.part_stride = w.Mp;
     for (int i = 0; i < c.layers; ++i) {
       const LayerW& L = m->layers[i];
       LnFold cons;
-      cons.stats = w.stats;
-      {
-        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
-        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
-      }
+      if ((rc = ln_consumer(m, s, VDR_K_GEMM_QKV, M, 3 * D, D, w, &cons))) return rc;
       cons.colsum = L.sqkv;
       if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons)))
         return rc;
@@ -671,10 +709,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
-      {
-        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
-        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
-      }
+      if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
                      sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
@@ -748,7 +783,6 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
   const int D = c.dim, F = c.mlp_hidden, H = c.heads, C = c.neck_chans;
   const int g = c.img / c.patch, n = g * g, ws = c.window, nw = (g + ws - 1) / ws, wtok = nw * nw * ws * ws;
   const int64_t M = (int64_t)mb * n;
-  const int groups = D / 64;
   int rc;
   VDR_TRY(hipMemsetAsync(w.h, 0, (size_t)mb * wtok * D * 2, s), "memset(window padding)");
   // fp8 (qkv / fc1 / fc2 on the block-scaled MFMA; out-projection, rel-pos GEMM, attention and neck stay bf16): the
@@ -837,12 +871,8 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
       continue;
     }
     if (m->ln_fuse) {
-      {
-        Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
-        VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, c.ln_eps, s), "ln_finalize");
-      }
       LnFold cons;
-      cons.stats = w.stats;
+      if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU, cons))) return rc;
     } else {

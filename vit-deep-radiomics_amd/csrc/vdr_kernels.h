@@ -33,6 +33,12 @@ struct GemmArgs {
   //   consumer side: y = r_m * (x.W'^T - mu_m * colsum) + bias', with (mu_m, r_m) = ln_stats[m]
   const float* ln_stats = nullptr;  // [M][2] fp32 (mean, rstd) or null
   const float* colsum = nullptr;    // [N] fp32: sum_k W'[n][k]
+  //   consumer side, statistics finalised inside the GEMM (ring3 variants 22-24, up to 16 groups): the producers'
+  //   partials instead of ln_stats; (mean, rstd) = what ln_finalize_kernel computes from them, bit for bit
+  const float* ln_cpart = nullptr;  // [ln_groups][ln_cstride][2] fp32 or null
+  int ln_groups = 0;
+  int64_t ln_cstride = 0;
+  float ln_inv_d = 0.0f, ln_eps = 0.0f;
   //   producer side: per output row and 64-column group, (sum, sum of squares) of the bf16 outputs
   float* ln_part = nullptr;         // [N/64][part_stride][2] fp32 or null
   int64_t part_stride = 0;
