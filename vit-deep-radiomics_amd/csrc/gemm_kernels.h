@@ -538,6 +538,7 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
 
   const int nsteps = p.K >> 5;
   const bool do_epi = __builtin_amdgcn_readfirstlane(p.abl & 1) == 0;
+  const bool skip_loads = __builtin_amdgcn_readfirstlane(p.abl & 4) != 0;  // diagnostic: the ring is filled once, then reused
   auto stage = [&](int slot) {
     char* d = smem + slot * UNIT;
 #pragma unroll
@@ -625,7 +626,7 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
     if (s + 1 < nsteps) {
       retire(s + 1, issued);
       __builtin_amdgcn_s_barrier();
-      if (s + NST < nsteps) {
+      if (s + NST < nsteps && !skip_loads) {
         stage(slot);
         issued = s + NST;
       }
