@@ -53,7 +53,7 @@ struct GemmK {
   int win_ws, win_g;  // SAM window un-partition of the output rows (0 = off)
   int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
   int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
-  int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units
+  int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units, 8 = skip the output stores
 };
 
 // Epilogue math for 4 consecutive output columns n..n+3 of output row m (v2 = SwiGLU gate partner).
@@ -314,6 +314,10 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   }
   int oc = n;
   if (E == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
+  if (p.abl & 8) {  // diagnostic: the whole epilogue except the global store (the value stays live through a never-true test)
+    if (o[0] == (bf16_t)12345.0f && o[7] == (bf16_t)-54321.0f) *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
+    return orow;
+  }
   if (p.nt_store) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc));
   else *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
   return orow;
