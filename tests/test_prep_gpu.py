@@ -185,6 +185,14 @@ def test_rotate_volume_bit_identical_to_scipy_and_goldens(golden_dir):
     assert ri.is_cuda and torch.equal(ri, img) and ri.data_ptr() != img.data_ptr() and torch.equal(rm, msk)
     ri, rm = pipeline.rotate_image(img, msk, 90)
     assert ri.is_cuda and rm.is_cuda and rm.dtype == torch.bool
+    # other angles SciPy accepts (negative, > 180, fractional), the smallest plane, and the refusal of integer volumes
+    v = rng.random((31, 29, 2))
+    for ang in (-30, 180, 270, 12.5):
+        assert np.array_equal(prep.rotate_volume(v, ang).cpu().numpy(), rotate(v, ang, axes=(0, 1), reshape=False, mode="nearest")), ang
+    tiny = rng.random((2, 2, 3))
+    assert np.array_equal(prep.rotate_volume(tiny, 45).cpu().numpy(), rotate(tiny, 45, axes=(0, 1), reshape=False, mode="nearest"))
+    with pytest.raises(TypeError):
+        prep.rotate_volume(np.zeros((8, 8, 2), np.int16), 45)
 
 
 def test_rotate_volume_ct_sized_slice_stack():

@@ -135,7 +135,9 @@ def rotate_volume(vol, angle, clip01=False, device=None) -> torch.Tensor:
     (numpy array or tensor; float64 / float32 / bool) on the GPU; returns a device tensor of the same dtype."""
     t = torch.as_tensor(vol)
     if t.dtype not in (torch.float64, torch.float32, torch.bool):
-        t = t.to(torch.float64)  # SciPy filters every other dtype in float64 as well; integer stores are not restated
+        # SciPy rounds and casts into an integer output array; the reference only rotates float images and boolean
+        # masks, so that store is not restated: refuse rather than return something SciPy would not
+        raise TypeError(f"rotate_volume: float64, float32 or bool volume, got {t.dtype}")
     t = t.to(device if device is not None else (t.device if t.is_cuda else "cuda"))
     rot, off = rotation_matrix_offset(t.shape[:2], angle)
     return affine_cubic(t, rot, off, clip01=clip01)
