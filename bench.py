@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Started plainly with --gpus N > 1 (no RANK / WORLD_SIZE in the environment) it launches the N ranks itself
+(vdr.dist.launch_ranks: fresh child processes of torch.distributed.run, created BEFORE this process makes any GPU
+call; this process only waits for them and returns their exit code).
+
 One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
 [256,3,224,224] bf16 per GPU -> vdr_forward (patch-embed, 12 pre-LN blocks, final LN + CLS slice)
 -> [256,768] fp32 CLS features; for N > 1 each rank processes its own 256 images (weak scaling,
@@ -107,20 +111,27 @@ def main():
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
     a = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torchrun / torch.distributed.run
+    if a.gpus > 1 and not launched:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (importing torch
+        # and vdr does not initialise HIP), the ranks are new child processes, and this process is not replaced.
+        from vdr.dist import launch_ranks
+        raise SystemExit(launch_ranks(os.path.abspath(__file__), a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libvdr has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         f"(one rank per GPU; --gpus {a.gpus} needs {a.gpus} devices)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # torchrun / torch.distributed.run
     if launched:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+        from vdr.dist import init_from_env
+        init_from_env("nccl", dev)  # nccl == RCCL on ROCm
 
     # a checkout without the built library (artefacts are git-ignored): build it once, rank 0 first, exactly as
     # __graft_entry__.build() does; the product itself never builds or falls back (vdr.load() raises without the .so)
@@ -244,6 +255,7 @@ def main():
                and not a.fp8 and not dense else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" + (" fp8 weights" if a.fp8 else "") if sam
                      else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} {'dense-descriptor' if dense else 'CLS-feature'} extraction"),
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "rccl_ranks": dist.get_world_size() if launched else 1,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": ("fp8 (MX e4m3 qkv/fc1/fc2" + ("/proj" if a.fp8 >= 2 else "") + ", bf16 elsewhere)") if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "

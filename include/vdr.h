@@ -24,7 +24,12 @@
  *     them alive until the stream has drained; the library owns only its packed
  *     weights;
  *   - all work is enqueued on the hipStream_t passed as `void* stream`
- *     (NULL = the null stream); no call synchronises the device;
+ *     (NULL = the null stream); the hot-path calls (vdr_forward*, vdr_op_*) never
+ *     synchronise the device, allocate or copy from the host: they can be captured
+ *     into a HIP graph from the first call on.  The load-time calls
+ *     (vdr_set_weight, vdr_finalize) are synchronous;
+ *   - a handle's calls run on the handle's device whatever device is current, and
+ *     leave the caller's current device unchanged;
  *   - a handle is bound to one device and is not thread-safe (one per rank).
  *   - there is NO CPU path in this library: with no HIP device every compute
  *     call fails with VDR_ERR_NO_DEVICE.
@@ -39,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 3
+#define VDR_ABI_VERSION 4
 
 typedef enum {
   VDR_OK = 0,
@@ -48,7 +53,7 @@ typedef enum {
   VDR_ERR_HIP = -3,          /* a HIP runtime call failed                   */
   VDR_ERR_UNKNOWN_NAME = -4, /* vdr_set_weight: name not part of the config */
   VDR_ERR_WORKSPACE = -5,    /* workspace too small                         */
-  VDR_ERR_INCOMPLETE = -6,   /* forward called before every weight was set  */
+  VDR_ERR_INCOMPLETE = -6,   /* a weight is missing / vdr_finalize has not run */
   VDR_ERR_UNSUPPORTED = -7   /* config outside what the kernels cover       */
 } vdr_status;
 
@@ -88,8 +93,8 @@ typedef struct {
   int32_t input_ln;   /* 1: LayerNorm applied to the assembled tokens before block 0          */
                       /*    (models_archs.py:145)                                             */
   float ln_eps;       /* 1e-6 timm/DINOv2/SAM, 1e-5 torch default (models_archs.py:136)       */
-  int32_t micro_batch;/* images per internal pass (0 = library default sized to the 256 MiB   */
-                      /* Infinity Cache); results do not depend on it                         */
+  int32_t micro_batch;/* images per internal pass (0 = library default: the whole batch, split   */
+                      /* evenly over `streams`); results do not depend on it                    */
   int32_t streams;    /* internal HIP streams the micro-batches are spread over (0/1 = the caller's   */
                       /* stream only); >1 lets kernels of independent micro-batches overlap, e.g. one */
                       /* GEMM's store-bound epilogue under another's MFMA main loop                   */
@@ -129,6 +134,13 @@ const char* vdr_last_error(vdr_handle h);
  * values in HOST memory in the PyTorch layout of that key; the library converts,
  * repacks and uploads (synchronously; this is load time, not the hot path). */
 int vdr_set_weight(vdr_handle h, const char* name, const float* host, const int64_t* shape, int ndim);
+
+/* Replaces: the end of load_state_dict / model.eval() (models_archs.py:32-35, tfds_dense_descriptor.py:89,105).
+ * Call once after the last vdr_set_weight (and again after any later vdr_set_weight): checks that every weight is
+ * set, folds LayerNorm into the consuming linears, builds the packed GEMM layouts / MX-fp8 copies / rel-pos tables.
+ * Synchronous (hipMalloc, hipMemcpy, hipDeviceSynchronize): this is load time.  vdr_forward* return
+ * VDR_ERR_INCOMPLETE until it has run. */
+int vdr_finalize(vdr_handle h);
 
 /* Number of weight tensors the config expects, and the i-th expected name. */
 int vdr_num_weights(vdr_handle h);
@@ -194,6 +206,14 @@ typedef enum {
 int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid,
                   const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
                   void* stream);
+/* The same with W in the library's packed weight layout — what vdr_finalize builds for every nn.Linear weight of a
+ * model: [N/2][K/32][2][32] bf16, so that a 128-byte line holds one 32-deep K block of two neighbouring rows and the
+ * operand loader of the GEMM touches whole lines.  vdr_op_pack_linear_weight converts W [N, K] bf16 (PyTorch layout)
+ * into `packed` (N*K bf16, device); N even, K % 32 == 0.  Results are bitwise those of vdr_op_linear. */
+int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream);
+int vdr_op_linear_packed(const void* x, const void* Wp, const float* bias, const void* resid,
+                         const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
+                         void* stream);
 
 /* ---- MX-fp8 operators (BASELINE config 5: "DINOv2 ViT-g/14 fp8 weights (CDNA4 fp8 MFMA)") ----------
  * An MX tensor X[rows, K] is an OCP e4m3 payload q[rows, K] (one byte per element) plus e8m0 scales, one per

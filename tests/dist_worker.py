@@ -1,0 +1,73 @@
+"""Rank process for the multi-rank tests, started by vdr.dist.launch_ranks (the launcher bench.py uses).
+
+    --backend gloo : CPU tensors; the per-rank "forward" is an identity on a known matrix (no GPU needed)
+    --backend nccl : one rank per GPU (RCCL); every rank runs the HIP forward on its batch shard, the shards are
+                     all-gathered and compared BITWISE with that rank's own forward of the whole batch
+
+Each rank writes {"rank", "world", "ok", ...} as JSON to <out>.<rank>; the test reads them back.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "vit-deep-radiomics_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--total", type=int, default=8)
+    ap.add_argument("--dim", type=int, default=5)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    from vdr.dist import all_gather_rows, extract_features_sharded, init_from_env, shard_bounds
+
+    rank, world, local_rank = init_from_env(a.backend)
+    res = {"rank": rank, "world": world, "backend": dist.get_backend(), "group_size": dist.get_world_size()}
+    try:
+        lo, hi = shard_bounds(a.total, rank, world)
+        if a.backend == "gloo":
+            full = torch.arange(a.total * a.dim, dtype=torch.float32).reshape(a.total, a.dim) * 0.5 - 3.0
+            calls = []
+
+            def fake_extract(local):  # stands in for the per-rank HIP forward
+                calls.append(local.shape[0])
+                return local.clone()
+
+            out = extract_features_sharded(fake_extract, full[lo:hi], a.total)
+            res["ok"] = bool(torch.equal(out, full) and out.is_contiguous() and calls == [hi - lo])
+        else:
+            import vdr
+            from oracle import vit_oracle as vo
+            torch.cuda.set_device(local_rank)
+            cfg = vo.VitCfg(64, 16, 3, 128, 2, 2, 512)
+            eng = vdr.Engine(vdr.VdrConfig(img=64, patch=16, dim=128, heads=2, layers=2, mlp_hidden=512))
+            eng.load_weights(vo.make_weights(cfg, seed=1, scale=0.05))
+            x = vo.make_images(cfg, a.total, seed=0).cuda()
+            whole = eng.forward(x, vdr.OUT_CLS)                       # the 1-rank result, on every rank
+            mine = eng.forward(x[lo:hi].contiguous(), vdr.OUT_CLS)    # this rank's shard
+            got = all_gather_rows(mine, a.total)
+            # an explicit collective even at world == 1 (all_gather_rows short-cuts there): RCCL itself is exercised
+            probe = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=mine.device) if (hi - lo) * world == a.total else None
+            if probe is not None:
+                dist.all_gather_into_tensor(probe, mine.contiguous())
+            torch.cuda.synchronize()
+            res["ok"] = bool(torch.equal(got, whole) and got.is_contiguous() and got.dtype == torch.float32
+                             and (probe is None or torch.equal(probe, whole)))
+            res["rows"] = [lo, hi]
+    finally:
+        with open(f"{a.out}.{rank}", "w") as f:
+            json.dump(res, f)
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,40 @@ def test_world2_gloo_allgather_reassembles_rows_bitwise(total):
     assert res == [(0, True), (1, True)]
 
 
+@pytest.mark.parametrize("world,total", [(2, 8), (2, 7), (3, 8)])  # equal shards, ragged tails, a world that does not divide N
+def test_launch_ranks_gloo_allgather_bitwise(tmp_path, world, total):
+    """The launcher bench.py uses for `--gpus N` (vdr.dist.launch_ranks -> torch.distributed.run children) with the
+    gloo backend: every rank's gathered matrix equals the unsharded one, rows in dataset order."""
+    import json
+    from vdr.dist import launch_ranks
+    out = str(tmp_path / "res")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    rc = launch_ranks(worker, world, ["--backend", "gloo", "--total", total, "--out", out], timeout=300)
+    assert rc == 0
+    res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    assert [r["rank"] for r in res] == list(range(world))
+    assert all(r["ok"] and r["world"] == world and r["group_size"] == world and r["backend"] == "gloo" for r in res)
+
+
+def test_bench_plain_multi_gpu_command_line_starts_the_ranks():
+    """`python bench.py --gpus 2` started plainly must itself start 2 ranks (here, without a GPU, each rank stops at
+    the 'needs an MI355X' check and the launcher reports failure) instead of running one rank and printing n_gpus 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box this test stays a CPU test
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    # torch.distributed.run stops the surviving rank as soon as the first one fails: one message is guaranteed, and its
+    # failure report names both local ranks
+    assert "bench.py needs an MI355X" in r.stderr, r.stderr[-2000:]
+    assert "local_rank: 0" in r.stderr and "local_rank: 1" in r.stderr, r.stderr[-2000:]
+    assert '"n_gpus"' not in r.stdout
+
+
 def test_pipeline_roi_host_logic_matches_reference_goldens(golden_dir):
     """vdr.pipeline's host-side box maths (extract_coords / extract_roi / crop_image) vs the reference's own
     functions (tests/golden/prep_roi.npz)."""

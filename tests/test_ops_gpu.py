@@ -86,36 +86,69 @@ def test_linear_exact_integers_catches_layout_bugs(ops):
     assert torch.equal(y.float().cpu(), _bf(W).float().t())
 
 
-@pytest.mark.parametrize("variant", list(range(1, 26)))
-def test_linear_every_tile_variant_exact(ops, variant):
-    """Every tile configuration the library can be asked for (legacy single/double-stage kernels, the ring
-    kernels, ring2 = 32x32x16 MFMA, ring3 = 16x16x32 MFMA) on integer data: bit-exact, with bias, GELU-free
-    residual epilogue and ragged edges in M and N."""
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("variant", [22, 23, 24, 25, 26, 27, 28])
+def test_linear_every_tile_variant_exact(ops, variant, packed):
+    """Every tile configuration the library ships (ring3 = LDS ring of 32-deep units, ring3k = K split across two wave
+    groups, ring4 = activations staged as 64-deep pieces) on integer data, with the weight in the PyTorch layout and in
+    the packed (pair-interleaved) layout: bit-exact, with bias, residual epilogue, ragged edges in M and N, and K from
+    one 64-deep piece (the ring never wraps) to many."""
     from vdr import EPI_BIAS, EPI_BIAS_RESID
     g = torch.Generator().manual_seed(variant)
-    for (M, N, K) in [(333, 776, 320), (64, 64, 64), (700, 1032, 128)]:
+    for (M, N, K) in [(333, 776, 320), (64, 64, 64), (700, 1032, 128), (130, 264, 192), (257, 512, 768)]:
         x = torch.randint(-2, 3, (M, K), generator=g).float()
         W = torch.randint(-2, 3, (N, K), generator=g).float()
         b = torch.randint(-3, 4, (N,), generator=g).float()
         r = torch.randint(-4, 5, (M, N), generator=g).float()
         ref = x @ W.t() + b
-        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS, variant=variant)
+        Wd = _bf(W).cuda()
+        if packed:
+            Wd = ops.pack_linear_weight(Wd)
+        y = ops.linear(_bf(x).cuda(), Wd, b.cuda(), epilogue=EPI_BIAS, variant=variant, packed=packed)
         assert torch.equal(y.float().cpu(), ref), f"variant {variant} bias {(M, N, K)}"
-        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=variant)
+        y = ops.linear(_bf(x).cuda(), Wd, b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=variant, packed=packed)
         assert torch.equal(y.float().cpu(), ref + r), f"variant {variant} resid {(M, N, K)}"
 
 
-def test_linear_mixed_tile_heights_exact(ops):
-    """Shapes with more than two tiles per CU make the default GEMM finish with a round of half-height
-    tiles (gemm_ring2_kernel); integer data -> bit-exact against the fp32 reference, every row."""
+def test_linear_rejects_unknown_and_ablation_variants(ops):
+    """The variant argument of the C ABI selects a shipped tile configuration; diagnostic encodings (>= 100, tuning
+    builds) and retired numbers are an error, never a silent garbage result."""
+    import vdr
+    x = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
+    for bad in (5, 21, 29, 122, 822):
+        with pytest.raises(vdr.VdrError):
+            ops.linear(x, x, None, variant=bad)
+
+
+def test_linear_full_size_packed_equals_plain_bitwise(ops):
+    """At the headline shapes (M = 50432) on random data: packed-weight ring4 (the forward's default) == plain-layout
+    ring3, bit for bit -- same products, same summation order, only the operand staging differs."""
+    from vdr import EPI_BIAS, EPI_BIAS_GELU
+    g = torch.Generator().manual_seed(11)
+    M = 50432
+    for (N, K, epi) in [(768, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (768, 3072, EPI_BIAS)]:
+        x = _bf(torch.randn(M, K, generator=g)).cuda()
+        W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        a = ops.linear(x, W, b, epilogue=epi, variant=22)
+        Wp = ops.pack_linear_weight(W)
+        for v in (22, 26, 27):
+            assert torch.equal(a, ops.linear(x, Wp, b, epilogue=epi, variant=v, packed=True)), (N, K, v)
+
+
+def test_linear_many_tiles_exact(ops):
+    """Shapes with more than two tiles per CU (several rounds of workgroups, a partial last round); integer data ->
+    bit-exact against the fp32 reference, every row."""
     from vdr import EPI_BIAS
     g = torch.Generator().manual_seed(3)
     for (M, N, K) in [(30000, 768, 128), (50432, 768, 64)]:
         x = torch.randint(-2, 3, (M, K), generator=g).float()
         W = torch.randint(-2, 3, (N, K), generator=g).float()
         b = torch.randint(-3, 4, (N,), generator=g).float()
-        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS)
-        assert torch.equal(y.float().cpu(), x @ W.t() + b), (M, N, K)
+        for v, packed in ((0, False), (26, True), (27, True)):
+            Wd = _bf(W).cuda()
+            y = ops.linear(_bf(x).cuda(), ops.pack_linear_weight(Wd) if packed else Wd, b.cuda(), epilogue=EPI_BIAS, variant=v, packed=packed)
+            assert torch.equal(y.float().cpu(), x @ W.t() + b), (M, N, K, v)
 
 
 SHAPES = [(197 * 3, 768, 768), (197 * 2 + 5, 2304, 768), (300, 3072, 768), (260, 768, 3072), (197, 192, 192),

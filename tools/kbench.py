@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--variants", type=str, default="0,2,3")
     ap.add_argument("--out", type=str, default="")
+    ap.add_argument("--packed", type=int, default=1, help="1: weights in the packed (pair-interleaved) layout, as in the forward")
+    ap.add_argument("--gemm-only", action="store_true")
     a = ap.parse_args()
     M, D = a.batch * a.seq, a.dim
     H = D // 64
@@ -49,12 +51,17 @@ def main():
         b = torch.randn(N, device=dev)
         r = torch.randn(M, N, device=dev).bfloat16() if epi == vdr.EPI_BIAS_RESID else None
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        Wp = ops.pack_linear_weight(W) if a.packed else W
         for v in [int(s) for s in a.variants.split(",")]:
-            med, mn = timeit(lambda: ops.linear(x, W, b, resid=r, epilogue=epi, variant=v, out=out))
+            med, mn = timeit(lambda: ops.linear(x, Wp, b, resid=r, epilogue=epi, variant=v, out=out, packed=bool(a.packed)))
             tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
             res[f"gemm_{name}_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
             print(f"gemm {name:5s} M{M} N{N} K{K} variant {v}: {med:8.3f} ms (min {mn:.3f})  {tf:7.1f} TFLOP/s", flush=True)
         del x, W, out
+    if a.gemm_only:
+        if a.out:
+            json.dump(res, open(a.out, "w"), indent=1)
+        return
     qkv = torch.randn(M, 3 * D, device=dev).bfloat16()
     for v in (3, 2, 1, 12, 22):
         med, mn = timeit(lambda: ops.attention(qkv, a.batch, a.seq, H, variant=v))

@@ -7,9 +7,18 @@
 
 namespace vdr {
 
+// diagnostic ablation bits exist in tuning builds only (-DVDR_TUNING, `make tuning`, used by tools/): the shipped
+// library compiles them out
+#ifdef VDR_TUNING
+#define VDR_ABL(p, bit) (__builtin_amdgcn_readfirstlane((p).abl & (bit)) != 0)
+#else
+#define VDR_ABL(p, bit) false
+#endif
+
 struct GemmK {
   const bf16_t* A;
   const bf16_t* W;
+  int w_il = 0;  // W is in the pair-interleaved layout [N/2][K/32][2][32] (gemm_kernels.h)
   const float* bias;
   const bf16_t* resid;
   const float* gamma;
@@ -24,8 +33,6 @@ struct GemmK {
   int tiles_n;
   int tiles_m = 0, gn = 0;  // gn > 0: tiles are walked in column groups of gn tile columns (see tile_of)
   int nwg;
-  int nwg_big;      // ring2: workgroups [0, nwg_big) use the full tile height, the rest half of it
-  int64_t m_split;  // ring2: first row covered by half-height tiles
   const float* ln_stats;
   const float* colsum;
   // LayerNorm fold with the (mean, rstd) finalisation inside the GEMM (ring3 kernels): the producers' (sum, sumsq)
@@ -51,74 +58,17 @@ struct GemmK {
   uint8_t* sC = nullptr;             // MX output: C is an e4m3 payload [M][ldc], sC its scales
   int64_t sc_rows = 0;
   int win_ws, win_g;  // SAM window un-partition of the output rows (0 = off)
-  int epi_lds;  // 1: LDS-staged epilogue, 0: direct (permlane32_swap) epilogue
-  int stagger;  // cycles the second resident layer of workgroups waits before its first tile (0 = off)
-  int abl;  // diagnostic ablation bits: 1 = skip the epilogue, 2 = skip the MFMAs, 4 = skip global loads after the first units, 8 = skip the output stores
+  int abl = 0;  // tuning builds: ablation bits, 1 = skip the epilogue, 4 = skip global loads after the first units, 8 = skip the output stores
 };
 
-// Epilogue math for 4 consecutive output columns n..n+3 of output row m (v2 = SwiGLU gate partner).
 // value of lane i + N inside the 16-lane DPP row (0 past the row end)
 template <int N>
 VDR_DEV float dpp_row_shl(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
 }
 
-template <int EPI>
-VDR_DEV void epi_quad(const GemmK& p, float (&v)[4], float (&u)[4], int64_t m, int n) {
-  if (m >= p.M || n >= p.N) return;
-  int64_t orow = m;
-  int prow = 0;
-  if (EPI == EPI_PATCH) {
-    const int64_t g = m / p.rpg;
-    const int i = (int)(m - g * p.rpg);
-    orow = g * p.gstride + p.off + i;
-    prow = p.off + i;
-  }
-  if (p.bias) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += b[e];
-  }
-  if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-  }
-  if (EPI == EPI_SWIGLU) {
-    // u is the gate partner (x2); its bias sits 32 packed rows further
-    if (p.bias) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias + n + 32);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] += b2[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = silu(v[e]) * u[e];
-  }
-  if (EPI == EPI_BIAS_RESID) {
-    if (p.gamma) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gm[e];
-    }
-    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.resid + orow * p.ldr + n);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-  }
-  if (EPI == EPI_PATCH) {
-    if (p.pos) {
-      const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)prow * p.N + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += ps[e];
-    }
-  }
-  bf16x4 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-  int oc = n;
-  if (EPI == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);  // packed column 64*blk + t (t < 32) -> feature 32*blk + t
-  *reinterpret_cast<bf16x4*>(p.C + orow * p.ldc + oc) = o;
-}
-
-// Same math for 8 consecutive columns n..n+7: residual read and output store are 16 bytes per lane
+// Epilogue math for 8 consecutive output columns n..n+7 of output row m (u = SwiGLU gate partner): residual read and
+// output store are 16 bytes per lane
 // (a store wave-instruction costs ~80-100 cycles of the CU's store path whatever its width, so the
 // epilogue is written with the widest ones).
 typedef __attribute__((ext_vector_type(8))) float f32x8;
@@ -314,30 +264,13 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   }
   int oc = n;
   if (E == EPI_SWIGLU) oc = (n >> 6) * 32 + (n & 31);
-  if (p.abl & 8) {  // diagnostic: the whole epilogue except the global store (the value stays live through a never-true test)
+  if (VDR_ABL(p, 8)) {  // diagnostic (tuning builds): the whole epilogue except the global store (the value stays live through a never-true test)
     if (o[0] == (bf16_t)12345.0f && o[7] == (bf16_t)-54321.0f) *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
     return orow;
   }
   if (p.nt_store) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc));
   else *reinterpret_cast<bf16x8*>(p.C + orow * p.ldc + oc) = o;
   return orow;
-}
-
-// Direct-from-accumulator epilogue: this lane owns row m and columns n_base + 8g + 4h + e of a
-// 32 (n) x 32 (m) accumulator tile.
-template <int EPI>
-VDR_DEV void epilogue_store(const GemmK& p, const f32x16& acc, const f32x16& acc2, int64_t m, int n_base,
-                            int h) {
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float v[4], u[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = acc[4 * g + e];
-      u[e] = acc2[4 * g + e];
-    }
-    epi_quad<EPI>(p, v, u, m, n_base + 8 * g + 4 * h);
-  }
 }
 
 // LDS-staged epilogue: the accumulators of a 32 (m) x 64 (n) block go through a wave-private fp32

@@ -233,11 +233,9 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.tiles_n = (a.N + BN - 1) / BN;
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
-  k.nwg = k.nwg_big = (int)nwg;
-  k.m_split = a.M;
+  k.nwg = (int)nwg;
   k.ln_part = a.ln_part;
   k.part_stride = a.part_stride;
-  k.epi_lds = 1;
   k.sA = (const uint8_t*)a.a_scale;
   k.sW = (const uint8_t*)a.w_scale;
   k.sa_rows = mx_rows_pad(a.M);
@@ -251,9 +249,11 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 #define VDR_LAUNCH_MX(E)                                                                                          \
   case E: {                                                                                                       \
     auto fn = gemm_mx_kernel<WAVES_M, WAVES_N, NST, E>;                                                           \
-    if (lds > 65536) {                                                                                            \
+    static bool attr_set = false; /* per instantiation: lds is a compile-time constant of it */                   \
+    if (lds > 65536 && !attr_set) {                                                                               \
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
       if (e != hipSuccess) return e;                                                                              \
+      attr_set = true;                                                                                            \
     }                                                                                                             \
     hipLaunchKernelGGL(fn, grid, block, lds, s, k);                                                               \
     break;                                                                                                        \

@@ -28,6 +28,20 @@ uint16_t f32_to_bf16(float f) {
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// entry points run on the handle's device whatever the caller's current device is, and leave that one current
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 enum WKind { W_VEC_F32, W_MAT_BF16, W_PATCH_BF16, W_W12_BF16, W_W12_BIAS, W_CONV3_BF16 };
@@ -77,6 +91,9 @@ struct vdr_model {
               *inw = nullptr, *inb = nullptr;
   bool resolved = false;
   bool ln_fuse = false;
+  // GEMM weights in the pair-interleaved layout the operand loader wants (gemm_kernels.h), keyed by the row-major
+  // device copy they were packed from; built by resolve()
+  std::map<const void*, void*> w_il;
   std::string err;
   // internal streams (cfg.streams > 1)
   std::vector<hipStream_t> streams;
@@ -195,10 +212,21 @@ const std::vector<float>* host_of(vdr_model* m, const std::string& name) {
   return it == m->index.end() ? nullptr : &m->slots[it->second].host;
 }
 
+// tuning knobs are read from the environment in tuning builds only (-DVDR_TUNING, `make tuning`); the shipped library
+// has no environment dependence
+int env_int(const char* name, int dflt) {
+#ifdef VDR_TUNING
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+
 bool ln_fusion_wanted(const vdr_model* m) {
   const vdr_config& c = m->cfg;
-  const char* e = getenv("VDR_LN_FUSE");
-  if (e && *e && atoi(e) == 0) return false;
+  if (env_int("VDR_LN_FUSE", 1) == 0) return false;
   return c.patch && c.pre_ln && !c.input_ln && !c.fp8 && (c.dim % 64) == 0;
 }
 
@@ -337,9 +365,49 @@ int resolve(vdr_model* m) {
     }
     VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
+  {
+    // pair-interleaved copies of every GEMM weight (whole-line operand loads, gemm_kernels.h)
+    VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+    const int D = c.dim, F = c.mlp_hidden;
+    const int N1 = c.act == VDR_ACT_SWIGLU ? 2 * F : F;
+    auto pack = [&](const void* w, int N, int K) -> int {
+      if (!w || (N & 1) || (K & 31)) return VDR_OK;
+      void*& dst = m->w_il[w];
+      if (!dst) VDR_TRY(hipMalloc(&dst, (size_t)N * K * 2 + 256), "hipMalloc(interleaved weight)");
+      VDR_TRY(launch_w_interleave(w, dst, N, K, K, nullptr), "w_interleave");
+      return VDR_OK;
+    };
+    int rc = VDR_OK;
+    if (c.patch && (rc = pack(m->w_patch, D, m->Kp))) return rc;
+    for (int i = 0; i < c.layers && !c.fp8; ++i) {
+      const LayerW& L = m->layers[i];
+      if ((rc = pack(L.wqkv, 3 * D, D)) || (rc = pack(L.wqkv_f, 3 * D, D))) return rc;  // (SAM blocks use the unfolded qkv)
+      if ((rc = pack(L.wproj, D, D))) return rc;
+      if ((rc = pack(L.w1, N1, D)) || (rc = pack(L.w1_f, N1, D))) return rc;
+      if ((rc = pack(L.w2, D, F))) return rc;
+    }
+    if (c.fp8 == 1)  // the out-projection stays bf16 at fp8 level 1
+      for (int i = 0; i < c.layers; ++i)
+        if ((rc = pack(m->layers[i].wproj, D, D))) return rc;
+    if (c.window > 0) {
+      if ((rc = pack(m->w_neck0, c.neck_chans, D))) return rc;
+      if ((rc = pack(m->w_neck2, c.neck_chans, 9 * c.neck_chans))) return rc;
+    }
+    VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
   for (auto& sl : m->slots) std::vector<float>().swap(sl.host);  // host copies are no longer needed
   m->resolved = true;
   return VDR_OK;
+}
+
+// every GEMM of the forward goes through here: the weight is swapped for its interleaved copy
+hipError_t launch_gemm_w(vdr_model* m, GemmArgs& g, int epi, int variant, hipStream_t s) {
+  auto it = m->w_il.find(g.W);
+  if (it != m->w_il.end()) {
+    g.W = it->second;
+    g.w_interleaved = 1;
+  }
+  return launch_gemm(g, epi, variant, s);
 }
 
 // ---- workspace carving ------------------------------------------------------------------------
@@ -470,11 +538,6 @@ struct Scope {
   }
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 // tile configuration per GEMM class; VDR_GEMM_VARIANT overrides all of them (tuning aid)
 int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   static const int forced = env_int("VDR_GEMM_VARIANT", -1);
@@ -529,7 +592,7 @@ struct LnFold {
 bool ln_stats_in_gemm(int cls, int64_t M, int N, int groups) {
   static const int mode = env_int("VDR_LN_IN_GEMM", -1);
   const int v = gemm_variant_for(cls, M, N);
-  if (mode == 0 || groups > 16 || v < 22 || v > 24) return false;
+  if (mode == 0 || groups > 16 || v < 22 || v == 25 || v > 28) return false;
   if (mode == 1) return true;
   return ((M + 127) / 128) * ((N + 255) / 256) <= 2048;
 }
@@ -581,7 +644,7 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
-  VDR_TRY(launch_gemm(g, epi, gemm_variant_for(cls, M, N), s), "gemm");
+  VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, M, N), s), "gemm");
   return VDR_OK;
 }
 
@@ -668,7 +731,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, proj_mx ? w.os : nullptr, lens, len_add), "attention");
       }
       if (proj_mx) {
@@ -705,7 +768,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
@@ -855,7 +918,7 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
         ga.part_stride = w.Mp;
       }
       Scope sc(m, s, VDR_K_GEMM_PROJ, 2.0 * T * D * D, 2.0 * ((double)T * D + (double)D * D + 2.0 * M * D));
-      VDR_TRY(launch_gemm(ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ, ga.M, ga.N), s), "proj gemm");
+      VDR_TRY(launch_gemm_w(m, ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ, ga.M, ga.N), s), "proj gemm");
     }
     if (fp8) {
       {
@@ -1004,7 +1067,7 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
 
 void vdr_destroy(vdr_handle h) {
   if (!h) return;
-  hipSetDevice(h->device);
+  DeviceGuard dg(h->device);
   for (auto& s : h->slots)
     if (s.dev) hipFree(s.dev);
   for (auto& L : h->layers) {
@@ -1018,6 +1081,8 @@ void vdr_destroy(vdr_handle h) {
     if (L.s1) hipFree(L.s1);
     if (L.t1) hipFree(L.t1);
   }
+  for (auto& kv : h->w_il)
+    if (kv.second) hipFree(kv.second);
   for (auto st : h->streams) hipStreamDestroy(st);
   for (auto e : h->ev_join) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1049,7 +1114,8 @@ int vdr_set_weight(vdr_handle m, const char* name, const float* host, const int6
   if (numel != s.numel)
     return fail(m, VDR_ERR_INVALID, std::string(name) + ": expected " + std::to_string(s.numel) + " elements, got " +
                                         std::to_string(numel));
-  VDR_TRY(hipSetDevice(m->device), "hipSetDevice");
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return fail(m, VDR_ERR_HIP, "hipSetDevice failed");
   std::vector<uint16_t> bf;
   std::vector<float> fv;
   const void* src = host;
@@ -1121,6 +1187,16 @@ int vdr_set_weight(vdr_handle m, const char* name, const float* host, const int6
   return VDR_OK;
 }
 
+int vdr_finalize(vdr_handle m) {
+  if (!m) return fail(m, VDR_ERR_INVALID, "null handle");
+  int rc = check_device(m);
+  if (rc) return rc;
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return fail(m, VDR_ERR_HIP, "hipSetDevice failed");
+  if (m->resolved) return VDR_OK;
+  return resolve(m);
+}
+
 int vdr_workspace_bytes(vdr_handle m, int batch, int seq, size_t* out) {
   if (!m || !out || batch <= 0) return fail(m, VDR_ERR_INVALID, "bad argument");
   const int ntok = m->cfg.patch ? m->n_tokens : seq + (m->cfg.has_cls ? 1 : 0);
@@ -1143,7 +1219,9 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     return fail(m, VDR_ERR_INVALID, "VDR_OUT_ENCODER is the output of a SAM encoder (window > 0); other models use CLS/DENSE/TOKENS");
   int rc = check_device(m);
   if (rc) return rc;
-  if (!m->resolved && (rc = resolve(m))) return rc;
+  if (!m->resolved) return fail(m, VDR_ERR_INCOMPLETE, "vdr_finalize has not run since the last vdr_set_weight");
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return fail(m, VDR_ERR_HIP, "hipSetDevice failed");
   const int mb_max = default_micro_batch(m, batch);
   const int ntok = m->n_tokens, n = m->n_patches, D = c.dim;
   const int ns = num_streams(m);
@@ -1196,7 +1274,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       }
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
-      VDR_TRY(launch_gemm(g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, g.M, g.N), s), "patch gemm");
+      VDR_TRY(launch_gemm_w(m, g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, g.M, g.N), s), "patch gemm");
     }
     if (pe_only) {
       if (out_dtype != VDR_BF16) {
@@ -1259,7 +1337,9 @@ static int forward_tokens_impl(vdr_handle m, const void* tokens, int in_dtype, i
   if (out_mode == VDR_OUT_CLS && !c.has_cls) return fail(m, VDR_ERR_INVALID, "model has no cls token");
   int rc = check_device(m);
   if (rc) return rc;
-  if (!m->resolved && (rc = resolve(m))) return rc;
+  if (!m->resolved) return fail(m, VDR_ERR_INCOMPLETE, "vdr_finalize has not run since the last vdr_set_weight");
+  DeviceGuard dg(m->device);
+  if (!dg.ok) return fail(m, VDR_ERR_HIP, "hipSetDevice failed");
   const int ncls = c.has_cls ? 1 : 0;
   const int ntok = seq + ncls, D = c.dim;
   const int mb_max = default_micro_batch(m, batch);
@@ -1325,17 +1405,21 @@ int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const 
   return VDR_OK;
 }
 
-int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid, const float* gamma, void* y,
-                  int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+static int op_linear_impl(const void* x, const void* W, int packed, const float* bias, const void* resid, const float* gamma,
+                          void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream) {
   if (!x || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
   if (epilogue < VDR_EPI_BIAS || epilogue > VDR_EPI_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "epilogue");
   if (epilogue == VDR_EPI_BIAS_RESID && !resid) return fail(nullptr, VDR_ERR_INVALID, "resid required");
   if (K % 64 || N % 8) return fail(nullptr, VDR_ERR_UNSUPPORTED, "K % 64 == 0 and N % 8 == 0 required");
+#ifndef VDR_TUNING
+  if (variant < 0 || variant >= 100) return fail(nullptr, VDR_ERR_INVALID, "variant");  // (ablation encodings: tuning builds only)
+#endif
   int rc = check_device(nullptr);
   if (rc) return rc;
   GemmArgs g{};
   g.A = x;
   g.W = W;
+  g.w_interleaved = packed;
   g.bias = bias;
   g.resid = resid;
   g.gamma = gamma;
@@ -1350,8 +1434,32 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
   g.omap = identity_map();
   if (variant == 0)  // library default: what the forward itself would pick for this shape
     variant = gemm_variant_for(N >= 2304 ? VDR_K_GEMM_QKV : VDR_K_GEMM_FC1, M, N);
-  OP_TRY(launch_gemm(g, epilogue, variant, (hipStream_t)stream), "gemm");
+  const hipError_t e = launch_gemm(g, epilogue, variant, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) {
+    (void)hipGetLastError();
+    return fail(nullptr, VDR_ERR_INVALID, "gemm: unknown tile variant or unsupported shape");
+  }
+  OP_TRY(e, "gemm");
   return VDR_OK;
+}
+
+int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid, const float* gamma, void* y,
+                  int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+  return op_linear_impl(x, W, 0, bias, resid, gamma, y, M, N, K, epilogue, variant, stream);
+}
+
+int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream) {
+  if (!W || !packed) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (N <= 0 || (N & 1) || K <= 0 || (K & 31)) return fail(nullptr, VDR_ERR_UNSUPPORTED, "N even and K % 32 == 0 required");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  OP_TRY(launch_w_interleave(W, packed, N, K, K, (hipStream_t)stream), "w_interleave");
+  return VDR_OK;
+}
+
+int vdr_op_linear_packed(const void* x, const void* Wp, const float* bias, const void* resid, const float* gamma, void* y,
+                         int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+  return op_linear_impl(x, Wp, 1, bias, resid, gamma, y, M, N, K, epilogue, variant, stream);
 }
 
 size_t vdr_prepare_scratch_bytes(int batch, int h, int w, int channels, int out_side) {

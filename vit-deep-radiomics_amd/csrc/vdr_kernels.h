@@ -19,7 +19,8 @@ enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_SWIGLU 
 
 struct GemmArgs {
   const void* A;      // [M, K] bf16, row stride lda
-  const void* W;      // [N, K] bf16 (PyTorch Linear layout), row stride ldw
+  const void* W;      // [N, K] bf16 (PyTorch Linear layout), row stride ldw; or the packed form (w_interleaved)
+  int w_interleaved = 0;  // W is [N/2][K/32][2][32] (launch_w_interleave): whole-line operand loads, gemm_kernels.h
   const float* bias;  // [N] or null
   const void* resid;  // [*, ldr] bf16 (EPI_BIAS_RESID), indexed by the OUTPUT row
   const float* gamma; // [N] LayerScale or null
@@ -57,7 +58,8 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
-int gemm_num_variants();
+// [N][K] bf16 (row stride ld elements) -> the pair-interleaved weight layout (N even, K % 32 == 0)
+hipError_t launch_w_interleave(const void* src, void* dst, int N, int K, int64_t ld, hipStream_t s);
 
 // y[r] = LN(x[imap(r)]) ; optional cls source: rows with r % cls_period == 0 read cls (fp32 [D])
 struct LnArgs {

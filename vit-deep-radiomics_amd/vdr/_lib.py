@@ -39,6 +39,7 @@ SYMBOLS = {
     "vdr_destroy": (None, [_P]),
     "vdr_last_error": (C.c_char_p, [_P]),
     "vdr_set_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
+    "vdr_finalize": (_I, [_P]),
     "vdr_num_weights": (_I, [_P]),
     "vdr_weight_name": (C.c_char_p, [_P, _I]),
     "vdr_workspace_bytes": (_I, [_P, _I, _I, C.POINTER(C.c_size_t)]),
@@ -47,6 +48,8 @@ SYMBOLS = {
     "vdr_forward_tokens_varlen": (_I, [_P, _P, _I, _I, _I, _P, _P, _I, _I, _P, C.c_size_t, _P]),
     "vdr_op_layernorm": (_I, [_P, _I, _P, _I, _P, _P, _L, _I, _F, _P]),
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "vdr_op_pack_linear_weight": (_I, [_P, _I, _I, _P, _P]),
+    "vdr_op_linear_packed": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_prepare_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "vdr_op_prepare_image": (_I, [_P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _I, _P, _P]),
     "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),
@@ -89,7 +92,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vdr_abi_version() != 3:
+    if lib.vdr_abi_version() != 4:
         raise ImportError("libvdr ABI version mismatch")
     _lib = lib
     return lib

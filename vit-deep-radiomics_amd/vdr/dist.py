@@ -7,8 +7,53 @@ the 1-rank result.
 """
 from __future__ import annotations
 
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(script: str, nproc: int, args=(), env=None, timeout=None) -> int:
+    """Start `nproc` fresh rank processes of `script` on this node (one per GPU) and wait for them:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script args`.
+    The ranks are CHILD processes created with subprocess (fork + exec of a new interpreter); the caller must not
+    have touched the GPU yet and is never replaced itself -- a process that has initialised HIP is not re-exec'd.
+    stdout / stderr of the ranks pass through.  Returns the launcher's exit code (0 = every rank exited 0)."""
+    e = dict(os.environ if env is None else env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
+        e.pop(k, None)  # a stale rendezvous in the caller's environment must not leak into the children
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    e.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *[str(a) for a in args]]
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode
+
+
+def init_from_env(backend: str = "nccl", device=None):
+    """Join the process group torch.distributed.run (or launch_ranks) prepared: RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_* from the environment.  backend "nccl" is RCCL on ROCm; "gloo" runs the same code on CPU tensors.
+    Returns (rank, world, local_rank)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=device if device is not None else torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
 
 
 def shard_bounds(total: int, rank: int, world: int):

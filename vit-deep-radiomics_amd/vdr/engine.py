@@ -106,6 +106,13 @@ class Engine:
             a = t.numpy()
             shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
             L.check(self.lib.vdr_set_weight(self.h, n.encode(), a.ctypes.data_as(C.c_void_p), shape, max(a.ndim, 1)), self.h)
+        if not missing:
+            self.finalize()
+
+    def finalize(self):
+        """vdr_finalize: LayerNorm folding, packed GEMM layouts, fp8 copies, rel-pos tables.  Load time (synchronous);
+        after it the forward calls neither allocate nor synchronise, so even the first one can be graph-captured."""
+        L.check(self.lib.vdr_finalize(self.h), self.h)
         self._loaded = True
 
     # ---- workspace ------------------------------------------------------------------------------

@@ -27,8 +27,19 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
-def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None):
-    """x [M,K] bf16, W [N,K] bf16 (for EPI_SWIGLU W/bias must already be gate-pair packed: see pack_w12)."""
+def pack_linear_weight(W: torch.Tensor) -> torch.Tensor:
+    """W [N, K] bf16 (PyTorch layout) -> the library's packed GEMM weight layout (what vdr_finalize builds for a
+    model's weights): [N/2][K/32][2][32], returned as an [N, K]-shaped opaque tensor."""
+    lib = L.load()
+    assert W.is_cuda and W.dtype == torch.bfloat16 and W.is_contiguous() and W.dim() == 2
+    Wp = torch.empty_like(W)
+    L.check(lib.vdr_op_pack_linear_weight(W.data_ptr(), W.shape[0], W.shape[1], Wp.data_ptr(), _s(W)))
+    return Wp
+
+
+def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None, packed=False):
+    """x [M,K] bf16, W [N,K] bf16 (for EPI_SWIGLU W/bias must already be gate-pair packed: see pack_w12).
+    packed=True: W is the result of pack_linear_weight (same values, whole-line operand loads)."""
     lib = L.load()
     assert x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_contiguous() and W.is_contiguous()
     M, K = x.shape
@@ -36,8 +47,8 @@ def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant
     assert W.shape[1] == K
     if out is None:
         out = torch.empty((M, N // 2 if epilogue == L.EPI_SWIGLU else N), dtype=torch.bfloat16, device=x.device)
-    L.check(lib.vdr_op_linear(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K,
-                              epilogue, variant, _s(x)))
+    fn = lib.vdr_op_linear_packed if packed else lib.vdr_op_linear
+    L.check(fn(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K, epilogue, variant, _s(x)))
     return out
 
 
