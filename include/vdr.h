@@ -115,6 +115,10 @@ typedef struct vdr_model* vdr_handle;
 /* ABI version of the loaded library (== VDR_ABI_VERSION it was built with). */
 int vdr_abi_version(void);
 
+/* 1 when the library was built with -DVDR_TUNING (tools/: diagnostic `variant` encodings >= 100 and VDR_* environment
+ * knobs exist), 0 for the shipped build (no environment dependence, unknown variants are an error). */
+int vdr_tuning_build(void);
+
 /* Number of visible gfx950 devices (0 when there is none; never fails). */
 int vdr_device_count(void);
 

@@ -166,3 +166,27 @@ def test_feature_metadata_table_layout(tmp_path):
     back = pd.read_parquet(path)
     assert list(back.columns) == list(df.columns) and len(back) == 60
     assert np.allclose(np.asarray(back["spatial_res"][0], dtype=float), res)
+
+
+def test_device_gelu_polynomial_matches_erf_gelu():
+    """The GEMM epilogue's erf-GELU (csrc/vdr_dev.h: max(x, 0) - a 2^Q(a), Q a degree-6 polynomial) restated in numpy
+    float32 from the coefficients in the device header, against the exact 0.5 x (1 + erf(x / sqrt 2)) in float64: the
+    relative error stays far below the bf16 rounding (2e-3) that follows it, the tail below the test's 5e-7."""
+    import re
+    from scipy.special import erf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "vit-deep-radiomics_amd", "csrc", "vdr_dev.h")).read()
+    body = src[src.index("VDR_DEV float gelu_erf(float x) {"):]
+    body = body[:body.index("}")]
+    coef = [np.float32(v) for v in re.findall(r"(-?\d\.\d+e[+-]\d+)f", body)]
+    assert len(coef) == 7 and "5.7f" in body
+    x = np.concatenate([np.linspace(-12, 12, 400001), np.array([-100.0, 100.0, 0.0])]).astype(np.float32)
+    a = np.minimum(np.abs(x), np.float32(5.7))
+    q = coef[0]
+    for c in coef[1:]:
+        q = (q * a + c).astype(np.float32)
+    got = (np.maximum(x, 0) - a * np.exp2(q.astype(np.float64)).astype(np.float32)).astype(np.float64)
+    ref = 0.5 * x.astype(np.float64) * (1.0 + erf(x.astype(np.float64) / np.sqrt(2.0)))
+    err = np.abs(got - ref)
+    assert (err <= 1e-4 * np.abs(ref) + 3e-7).all(), float((err / (np.abs(ref) + 3e-3)).max())
+    assert err.max() < 8e-6

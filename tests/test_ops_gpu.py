@@ -105,9 +105,10 @@ def test_linear_every_tile_variant_exact(ops, variant, packed):
         if packed:
             Wd = ops.pack_linear_weight(Wd)
         y = ops.linear(_bf(x).cuda(), Wd, b.cuda(), epilogue=EPI_BIAS, variant=variant, packed=packed)
-        assert torch.equal(y.float().cpu(), ref), f"variant {variant} bias {(M, N, K)}"
+        # integer sums are exact in fp32; the only rounding is the final one to bf16 (a no-op while |y| <= 256)
+        assert torch.equal(y.float().cpu(), _bf(ref).float()), f"variant {variant} bias {(M, N, K)}"
         y = ops.linear(_bf(x).cuda(), Wd, b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=variant, packed=packed)
-        assert torch.equal(y.float().cpu(), ref + r), f"variant {variant} resid {(M, N, K)}"
+        assert torch.equal(y.float().cpu(), _bf(ref + r).float()), f"variant {variant} resid {(M, N, K)}"
 
 
 def test_linear_rejects_unknown_and_ablation_variants(ops):
@@ -115,7 +116,8 @@ def test_linear_rejects_unknown_and_ablation_variants(ops):
     builds) and retired numbers are an error, never a silent garbage result."""
     import vdr
     x = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
-    for bad in (5, 21, 29, 122, 822):
+    tuning = bool(vdr.load().vdr_tuning_build())  # a tools/ build accepts the ablation encodings
+    for bad in (5, 21, 29) + (() if tuning else (122, 822)):
         with pytest.raises(vdr.VdrError):
             ops.linear(x, x, None, variant=bad)
 

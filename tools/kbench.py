@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--out", type=str, default="")
     ap.add_argument("--packed", type=int, default=1, help="1: weights in the packed (pair-interleaved) layout, as in the forward")
     ap.add_argument("--gemm-only", action="store_true")
+    ap.add_argument("--rounds", type=int, default=15)
     a = ap.parse_args()
     M, D = a.batch * a.seq, a.dim
     H = D // 64
@@ -45,6 +46,9 @@ def main():
     torch.manual_seed(0)
     shapes = {"qkv": (3 * D, D, vdr.EPI_BIAS), "proj": (D, D, vdr.EPI_BIAS_RESID), "fc1": (4 * D, D, vdr.EPI_BIAS_GELU),
               "fc2": (D, 4 * D, vdr.EPI_BIAS_RESID)}
+    # interleaved rounds in ONE process (guide rule 24): every round times each (shape, variant) once, so clock /
+    # thermal drift hits all variants alike; report the median and the minimum over the rounds
+    cases = []
     for name, (N, K, epi) in shapes.items():
         x = torch.randn(M, K, device=dev).bfloat16()
         W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
@@ -53,11 +57,30 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         Wp = ops.pack_linear_weight(W) if a.packed else W
         for v in [int(s) for s in a.variants.split(",")]:
-            med, mn = timeit(lambda: ops.linear(x, Wp, b, resid=r, epilogue=epi, variant=v, out=out, packed=bool(a.packed)))
-            tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
-            res[f"gemm_{name}_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
-            print(f"gemm {name:5s} M{M} N{N} K{K} variant {v}: {med:8.3f} ms (min {mn:.3f})  {tf:7.1f} TFLOP/s", flush=True)
-        del x, W, out
+            cases.append((name, N, K, v, (lambda x=x, Wp=Wp, b=b, r=r, epi=epi, v=v, out=out:
+                                          ops.linear(x, Wp, b, resid=r, epilogue=epi, variant=v, out=out, packed=bool(a.packed)))))
+    for c in cases:
+        c[4]()
+    torch.cuda.synchronize()
+    times = [[] for _ in cases]
+    for rnd in range(a.rounds):
+        evs = []
+        for c in cases:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            c[4]()
+            c[4]()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        for i, (e0, e1) in enumerate(evs):
+            times[i].append(e0.elapsed_time(e1) / 2)
+    for (name, N, K, v, _), ts in zip(cases, times):
+        ts = sorted(ts)
+        med, mn = ts[len(ts) // 2], ts[0]
+        tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
+        res[f"gemm_{name}_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
+        print(f"gemm {name:5s} M{M} N{N} K{K} variant {v:4d}: {med:8.4f} ms (min {mn:.4f})  {tf:7.1f} TFLOP/s", flush=True)
     if a.gemm_only:
         if a.out:
             json.dump(res, open(a.out, "w"), indent=1)

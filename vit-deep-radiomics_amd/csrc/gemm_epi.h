@@ -413,6 +413,93 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
   }
 }
 
+// bf16-staged epilogue for the write-once outputs (EPI_BIAS = qkv, EPI_BIAS_GELU = fc1: 232 and 310 MB per launch at
+// the headline shapes).  The whole epilogue arithmetic (LayerNorm fold, bias, erf-GELU) runs in the ACCUMULATOR layout
+// -- lane (r = lane & 15, q = lane >> 4) owns rows 16 it + r and columns 16 jt + 4 q + e of the 64 x 64 wave tile, so the
+// per-column constants are 4 x f32x4 and the per-row statistics 4 pairs per lane -- and only the final bf16 values go
+// through LDS: a wave-private [64 rows][128 B] image, 8-byte writes, 16-byte read-back with 8 lanes per row, whole
+// 128-B lines to memory.  Half the LDS bytes of the fp32 staging of epilogue_lds (the LDS write port, ~80 B/clk per
+// CU, is what that staging waits for).  16-B slot s of row r sits at slot s ^ ((r >> 1) & 7): conflict-free
+// read-back, 2-way on the writes (rows 2k / 2k+1), which an 8-byte write hides.
+// Epilogues that add a residual keep the fp32 staging: the sum has to be rounded once, after the add.
+template <int EPI>
+VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t m_base, int n_base, int lane,
+                           const float2* tile_stats = nullptr) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "write-once outputs only");
+  const int r15 = lane & 15, q4 = lane >> 4;
+  f32x4 bias[4], csum[4];
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    int n = n_base + jt * 16 + 4 * q4;
+    n = n < p.N ? n : 0;  // out-of-range columns are never stored; keep the address valid
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    bias[jt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z;
+    csum[jt] = p.ln_fold ? *reinterpret_cast<const f32x4*>(p.colsum + n) : z;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    float mu = 0.0f, rs = 1.0f;
+    if (tile_stats) {
+      const float2 t = tile_stats[it * 16 + r15];
+      mu = t.x;
+      rs = t.y;
+    } else if (p.ln_stats) {
+      int64_t m = m_base + it * 16 + r15;
+      m = m < p.M ? m : p.M - 1;
+      const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
+      mu = t.x;
+      rs = t.y;
+    }
+    const int row = it * 16 + r15;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc.t[jt][it][e];
+        if (p.ln_fold) v = rs * (v - mu * csum[jt][e]);
+        v += bias[jt][e];
+        if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+        o[e] = (bf16_t)v;
+      }
+      const int slot = (2 * jt + (q4 >> 1)) ^ ((row >> 1) & 7);
+      *reinterpret_cast<bf16x4*>(stg + row * 128 + slot * 16 + (q4 & 1) * 8) = o;
+    }
+  }
+  // read-back: 8 lanes per row, 8 rows per instruction
+  const int c8 = lane & 7;
+  const int n = n_base + c8 * 8;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = rr * 8 + (lane >> 3);
+    const bf16x8 o = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ ((row >> 1) & 7)) * 16));
+    const int64_t m = m_base + row;
+    if (m < p.M && n < p.N) {
+      bf16x8* dst = reinterpret_cast<bf16x8*>(p.C + m * p.ldc + n);
+      if (VDR_ABL(p, 8)) {
+        if (o[0] == (bf16_t)12345.0f && o[7] == (bf16_t)-54321.0f) *dst = o;
+      } else if (p.nt_store) {
+        __builtin_nontemporal_store(o, dst);
+      } else {
+        *dst = o;
+      }
+    }
+  }
+}
+
+// which epilogue a ring3 / ring4 tile takes
+template <int EPI>
+VDR_DEV void epilogue_tile(const GemmK& p, const Acc16& acc, char* smem, int wave, int64_t m_base, int n_base, int lane,
+                           const float2* tile_stats = nullptr) {
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if (!p.out_f32 && p.win_ws == 0 && !p.ln_part) {
+      epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m_base, n_base, lane, tile_stats);
+      return;
+    }
+  }
+  epilogue_lds<EPI, 2, 2>(p, acc, smem + wave * (32 * 272), m_base, n_base, lane, tile_stats);
+}
+
 // logical tile id -> (tile row, tile column).  gn == 0: row-major (the column tiles of a tile row are neighbours and
 // share the A panel; right when the whole W fits the XCD's L2 or K is long).  gn > 0: column groups of gn tile
 // columns are swept over all tile rows before the next group starts: the gn W panels of a group stay resident in

@@ -49,7 +49,7 @@ VDR_DEV const bf16_t* w_unit_src(const GemmK& p, int gr, int c) {
 // -------------------------------------------------------------------------------------------------
 template <int WAVES_M, int WAVES_N, int NST, int EPI>
 VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, char* smem) {
-  constexpr int TM = 2, TN = 2;  // in units of 32: the wave tile is 64 x 64
+  // the wave tile is 64 x 64 = 4 x 4 MFMA tiles
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * 64;
   constexpr int BN = WAVES_N * 64;
@@ -216,8 +216,8 @@ VDR_DEV void gemm_ring3_body(const GemmK& p, const int64_t m0, const int n0, cha
 
   if (!do_epi && acc.t[0][0][0] != 12345.678f) return;  // ablation: no epilogue (keeps acc live)
   __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
-  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane,
-                            p.ln_cpart ? reinterpret_cast<const float2*>(smem + p.stats_off) + wm * 64 : nullptr);
+  epilogue_tile<EPI>(p, acc, smem, wave, m0 + wm * 64, n0 + wn * 64, lane,
+                     p.ln_cpart ? reinterpret_cast<const float2*>(smem + p.stats_off) + wm * 64 : nullptr);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -390,7 +390,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring3_kernel(Ge
 // -------------------------------------------------------------------------------------------------
 template <int WAVES_M, int WAVES_N, int EPI>
 VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, char* smem) {
-  constexpr int TM = 2, TN = 2;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * 64;
   constexpr int BN = WAVES_N * 64;
@@ -568,8 +567,8 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
     if (tid < BM) reinterpret_cast<float2*>(smem + STATS_OFF)[tid] = my_stats;
     __syncthreads();
   }
-  epilogue_lds<EPI, TM, TN>(p, acc, smem + wave * (32 * 272), m0 + wm * 64, n0 + wn * 64, lane,
-                            p.ln_cpart ? reinterpret_cast<const float2*>(smem + STATS_OFF) + wm * 64 : nullptr);
+  epilogue_tile<EPI>(p, acc, smem, wave, m0 + wm * 64, n0 + wn * 64, lane,
+                     p.ln_cpart ? reinterpret_cast<const float2*>(smem + STATS_OFF) + wm * 64 : nullptr);
 }
 
 template <int WAVES_M, int WAVES_N, int EPI>

@@ -561,14 +561,11 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   const int o = cls == VDR_K_GEMM_QKV ? o_qkv : cls == VDR_K_GEMM_PROJ ? o_proj : cls == VDR_K_GEMM_FC1 ? o_fc1
                 : cls == VDR_K_GEMM_FC2 ? o_fc2 : -1;
   if (o >= 0) return o;
-  // ring3 = the ring2 pipeline on the 16x16x32 MFMA shape (the chip holds a higher clock on it): measured in the
-  // full forward, same box: qkv 2.64 -> 2.40 ms, fc1 3.96 -> 3.74, fc2 3.48 -> 3.36, proj 1.39 -> 1.37 per step
-  switch (cls) {
-    case VDR_K_GEMM_QKV:
-      return 23;  // ring3 256x256, 16 waves, 3 x 32 KB ring
-    default:
-      return 22;  // ring3 128x256, 8 waves, 3 x 24 KB ring, 2 workgroups per CU
-  }
+  // ring4 (whole-line operand staging: packed weights + 64-deep activation pieces), 128x256 tile, 8 waves, two
+  // workgroups per CU.  Measured at M = 50432, interleaved rounds in one process, weights packed in both arms
+  // (tools/kbench.py): against ring3 128x256 qkv 0.195 -> 0.184 ms, proj 0.098 -> 0.075, fc1 0.290 -> 0.276, fc2
+  // 0.249 -> 0.221; the 256x256 forms (ring3 23, ring4 27) lose on every shape.
+  return 26;
 }
 
 struct LnFold {
@@ -1002,6 +999,14 @@ int check_device(vdr_handle h) {
 extern "C" {
 
 int vdr_abi_version(void) { return VDR_ABI_VERSION; }
+
+int vdr_tuning_build(void) {
+#ifdef VDR_TUNING
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int vdr_device_count(void) {
   int n = 0;
@@ -1645,7 +1650,7 @@ int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const fl
   a.ldc = D;
   a.ldr = D;
   a.omap = RowMap{n, row_stride, row_offset};
-  OP_TRY(launch_gemm(a, EPI_PATCH, 0, (hipStream_t)stream), "patch gemm");
+  OP_TRY(launch_gemm(a, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, a.M, a.N), (hipStream_t)stream), "patch gemm");
   return VDR_OK;
 }
 

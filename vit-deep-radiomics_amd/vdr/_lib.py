@@ -34,6 +34,7 @@ class vdr_config(C.Structure):
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "vdr_abi_version": (_I, []),
+    "vdr_tuning_build": (_I, []),
     "vdr_device_count": (_I, []),
     "vdr_create": (_I, [C.POINTER(vdr_config), _I, C.POINTER(_P)]),
     "vdr_destroy": (None, [_P]),
