@@ -99,9 +99,8 @@ def main():
     ap.add_argument("--model", type=str, default="vit_base16_224")
     ap.add_argument("--micro-batch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0)
-    ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0,
-                    help="1: qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline "
-                         "dtype); 2: the out-projection too")
+    ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0, choices=[0, 1],
+                    help="1: qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline dtype)")
     ap.add_argument("--out", choices=["cls", "dense"], default="cls",
                     help="cls: [N, D] CLS features (headline); dense: [N, n*D] per-patch descriptors (BASELINE config 4)")
     ap.add_argument("--input", choices=["bf16", "fp32"], default="bf16",
@@ -257,7 +256,7 @@ def main():
                "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "rccl_ranks": dist.get_world_size() if launched else 1,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": ("fp8 (MX e4m3 qkv/fc1/fc2" + ("/proj" if a.fp8 >= 2 else "") + ", bf16 elsewhere)") if a.fp8 else "bf16", "data": "synthetic",
+               "dtype": "fp8 (MX e4m3 qkv/fc1/fc2, bf16 elsewhere)" if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
                                        f"[{total},64,64,256] fp32" if sam else
                                        f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, {'dense per-patch descriptors' if dense else 'CLS-token extraction'} -> [{total},{D}] fp32")

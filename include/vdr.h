@@ -104,8 +104,12 @@ typedef struct {
   int32_t global_mask;/* bit i set: block i attends over the whole grid (SAM ViT-B: 2,5,8,11 = 0x924)  */
   int32_t neck_chans; /* output channels of the conv neck (256); 1x1 conv, LN2d, 3x3 conv, LN2d        */
   /* BASELINE config 5 ("fp8 weights (CDNA4 fp8 MFMA)"): */
-  int32_t fp8;        /* 1: qkv / fc1 (w12) / fc2 (w3) — 2: also the out-projection — weights are kept as MX-fp8 (OCP e4m3 + e8m0 scale per 32 K      */
-                      /* elements) and run on v_mfma_scale_f32_32x32x64_f8f6f4 with MX-fp8 activations; pre_ln only    */
+  int32_t fp8;        /* 1: the qkv / fc1 (w12) / fc2 (w3) weights are kept as MX-fp8 (OCP e4m3 + e8m0 scale per 32 K    */
+                      /* elements) and run on v_mfma_scale_f32_32x32x64_f8f6f4 with MX-fp8 activations; the            */
+                      /* out-projection, attention and the residual stream stay bf16; pre_ln only; 0 or 1             */
+  int32_t no_ln_fold; /* 0 (default): pre-LN image models fold norm1 / norm2 into the qkv / fc1 GEMMs (the producers of    */
+                      /* the residual stream leave row statistics, gamma goes into the weights: no LayerNorm pass);     */
+                      /* 1: keep the explicit LayerNorm kernel (numerics A/B, tests)                                    */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

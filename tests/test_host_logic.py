@@ -16,10 +16,12 @@ def test_expected_weight_shapes_match_oracle_for_every_named_config():
     import vdr
     from vdr.weights import expected_weight_shapes
     for name, ocfg in vo.CONFIGS.items():
-        key = "dinov2" if name == "dinov2_small14_896" else name
-        vcfg = vdr.ARCHS[key]
+        vcfg = vdr.ARCHS[name]
         assert expected_weight_shapes(vcfg) == vo.weight_shapes(ocfg), name
         assert vcfg.n_tokens == ocfg.n_tokens
+    # model_name 'dinov2' is what the reference runs of that backbone: model.patch_embed only (tfds_dense_descriptor.py:128)
+    assert sorted(expected_weight_shapes(vdr.ARCHS["dinov2"])) == ["patch_embed.proj.bias", "patch_embed.proj.weight"]
+    assert vdr.ARCHS["dinov2"].n_patches == 4096
 
 
 def test_torch_encoder_state_dict_translation():

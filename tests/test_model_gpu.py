@@ -36,12 +36,12 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
                        has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
-                       micro_batch=micro_batch, fp8=fp8)
+                       micro_batch=micro_batch, fp8=fp8, ln_fold=ln_fold)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -87,6 +87,37 @@ def test_small_vit_all_outputs(name):
     # bf16 input images and bf16 outputs take the same path
     d16 = e.forward(xd.to(torch.bfloat16), vdr.OUT_DENSE, torch.bfloat16)
     assert d16.dtype == torch.bfloat16 and _rel_l2(d16.float().cpu(), ref["dense"]) < 3e-2
+
+
+def test_first_forward_after_finalize_is_graph_capturable():
+    """include/vdr.h: the hot-path calls never synchronise, allocate or copy from the host.  The FIRST vdr_forward after
+    load (vdr_finalize did the load-time work) is captured into a HIP graph -- a hipMalloc / hipMemcpy /
+    hipDeviceSynchronize inside it would fail the capture -- and the replay reproduces an eager forward bit for bit."""
+    import vdr
+    cfg = SMALL["p16_d128"]
+    vcfg = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
+                         mlp_hidden=cfg.mlp_hidden)
+    w = vo.make_weights(cfg, seed=3, scale=0.05)
+    x = vo.make_images(cfg, 5, seed=2).cuda()
+    e = vdr.Engine(vcfg)
+    with pytest.raises(vdr.VdrError):  # nothing loaded, not finalised: an error, not a lazy resolve
+        e.forward(x, vdr.OUT_CLS)
+    e.load_weights(w)  # ends with vdr_finalize
+    out = torch.empty((5, cfg.dim), dtype=torch.float32, device="cuda")
+    e._workspace(5)  # the caller-owned workspace exists before the capture (torch allocation, not the library's)
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            e.forward_into(x, out, vdr.OUT_CLS)
+    torch.cuda.current_stream().wait_stream(side)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    eager = vdr.Engine(vcfg)
+    eager.load_weights(w)
+    assert torch.equal(out, eager.forward(x, vdr.OUT_CLS))
 
 
 def test_micro_batching_does_not_change_results():
@@ -189,7 +220,7 @@ def test_fp8_small_vit_all_outputs(name):
     x = vo.make_images(cfg, 5, seed=4)
     ref = vo.forward_images(cfg, w, x)
     xd = x.cuda()
-    for level, mode in ((1, "mx"), (2, "mx2")):
+    for level, mode in ((1, "mx"),):
         emx = vo.forward_images(cfg, w, x, emulate_bf16=mode)
         e = _engine(cfg, w, fp8=level)
         _gate_fp8(e.forward(xd, vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{name} fp8={level} cls")
@@ -210,7 +241,7 @@ def test_fp8_dinov2_giant14_config5_geometry():
         w = vo.make_weights(cfg, seed=6)
         x = vo.make_images(cfg, 3, seed=7)
         ref = vo.forward_images(cfg, w, x)
-        for level, mode in ((1, "mx"), (2, "mx2")):
+        for level, mode in ((1, "mx"),):
             emx = vo.forward_images(cfg, w, x, emulate_bf16=mode)
             e = _engine(cfg, w, fp8=level)
             _gate_fp8(e.forward(x.cuda(), vdr.OUT_CLS), ref["cls"], emx["cls"], cfg.layers, f"{tag} fp8={level} cls")
@@ -224,9 +255,9 @@ def test_fp8_is_refused_where_it_is_not_implemented():
                                  input_ln=True, fp8=True))
 
 
-def test_layernorm_folding_matches_the_explicit_layernorm_path(monkeypatch):
+def test_layernorm_folding_matches_the_explicit_layernorm_path():
     """Pre-LN image models fold LayerNorm into the qkv / fc1 GEMMs (row statistics from the producer's
-    epilogue, gamma folded into the weights).  VDR_LN_FUSE=0 keeps the explicit LayerNorm kernel: both
+    epilogue, gamma folded into the weights).  vdr_config.no_ln_fold = 1 keeps the explicit LayerNorm kernel: both
     paths must agree to bf16 noise, also when the token rows carry a mean several sigma away from 0
     (variance is formed as E[x^2] - mean^2 from fp32 partial sums)."""
     import vdr
@@ -236,9 +267,8 @@ def test_layernorm_folding_matches_the_explicit_layernorm_path(monkeypatch):
     x = vo.make_images(cfg, 6, seed=13)
     ref = vo.forward_images(cfg, w, x)
     fused = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
-    monkeypatch.setenv("VDR_LN_FUSE", "0")
-    plain = _engine(cfg, w).forward(x.cuda(), vdr.OUT_TOKENS)
-    monkeypatch.delenv("VDR_LN_FUSE")
+    plain = _engine(cfg, w, ln_fold=False).forward(x.cuda(), vdr.OUT_TOKENS)
+    assert not torch.equal(fused, plain)  # two different code paths really ran
     # rows with mean 1.5 keep fewer bf16 bits for their spread: both paths sit ~1.5x above the usual gate
     g = 1.5 * gate_l2(cfg.layers)
     r_f, r_p = _rel_l2(fused.cpu(), ref["tokens"]), _rel_l2(plain.cpu(), ref["tokens"])
@@ -290,8 +320,22 @@ def test_golden_reference_class_tokens(golden_dir, tag):
             sd[d + n + ".weight"], sd[d + n + ".bias"] = w[s + n + ".weight"], w[s + n + ".bias"]
     for k in ("dense1.weight", "dense1.bias", "dense2.weight", "dense2.bias"):
         sd["classifier." + k] = torch.from_numpy(g["head.classifier." + k])
-    m = vdr.TransformerNoduleClassifier(dim, ffn, heads, 2, layers, sd)
+    # the reference's own flow (train_models.py:455-486 build_model, models_archs.py:32-35 load): construct with the
+    # reference signature, then load_state_dict(torch.load(path)); calling the model before that is an error
+    m = vdr.TransformerNoduleClassifier(input_dim=dim, dim_feedforward=ffn, num_heads=heads, num_classes=2, num_layers=layers)
+    with pytest.raises(RuntimeError):
+        m(x.cuda())
+    import io
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    m.load_state_dict(torch.load(buf, map_location="cuda", weights_only=True))
+    m = m.to("cuda").eval()
+    assert sorted(m.state_dict()) == sorted(sd)
     logits, cls2 = m(x.cuda())
+    # the constructor shortcut gives the same model
+    m2 = vdr.TransformerNoduleClassifier(dim, ffn, heads, 2, layers, state_dict=sd)
+    assert torch.equal(m2(x.cuda())[1], cls2)
     assert logits.shape == (int(g["batch"]), 2) and cls2.shape == (int(g["batch"]), dim)
     assert torch.equal(cls2, cls)
     err = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
@@ -377,6 +421,50 @@ def test_reference_boundary_protocol():
         model.patch_embed(torch.zeros(1, 3, 100, 100).cuda())
     with pytest.raises(KeyError):
         vdr.load_model("vit_tiny16_224", weights={k: v for k, v in w.items() if k != "norm.bias"})
+    # forward_into (the all-gather path) validates instead of converting: wrong dtype / size / layout are errors
+    eng = model.engine
+    xin = x.cuda()
+    with pytest.raises(TypeError):
+        eng.forward_into(xin.double(), torch.empty(2, 192, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.forward_into(xin, torch.empty(1, 192, device="cuda"))            # too small: would be an OOB write
+    with pytest.raises(ValueError):
+        eng.forward_into(xin, torch.empty(2, 384, device="cuda")[:, ::2])    # not contiguous
+    ok = eng.forward_into(xin, torch.empty(2, 192, device="cuda"))
+    assert torch.equal(ok, eng.forward(xin, vdr.OUT_CLS))
+
+
+def test_dinov2_reference_mode_loads_a_real_checkpoint_layout():
+    """The reference's 'dinov2' mode (tfds_dense_descriptor.py:70-90, 128-133): torch.hub dinov2_vits14, of which only
+    `model.patch_embed(x)` runs, at 896^2.  A state_dict with that checkpoint's REAL key set and shapes (random values;
+    pos_embed is [1, 1370, 384] = 518^2 / 14 + cls, which no 896^2 token model could take as it is) must load, and
+    patch_embed must equal F.conv2d(stride 14) -> flatten -> transpose on the same bf16-rounded operands."""
+    import vdr
+    g = torch.Generator().manual_seed(5)
+    D, L, F = 384, 12, 1536
+    sd = {"cls_token": torch.randn(1, 1, D, generator=g), "pos_embed": torch.randn(1, 1370, D, generator=g) * 0.02,
+          "mask_token": torch.zeros(1, D), "patch_embed.proj.weight": torch.randn(D, 3, 14, 14, generator=g) * 0.05,
+          "patch_embed.proj.bias": torch.randn(D, generator=g) * 0.1, "norm.weight": torch.ones(D), "norm.bias": torch.zeros(D)}
+    for i in range(L):
+        p = f"blocks.{i}."
+        sd.update({p + "norm1.weight": torch.ones(D), p + "norm1.bias": torch.zeros(D), p + "attn.qkv.weight": torch.zeros(3 * D, D),
+                   p + "attn.qkv.bias": torch.zeros(3 * D), p + "attn.proj.weight": torch.zeros(D, D), p + "attn.proj.bias": torch.zeros(D),
+                   p + "ls1.gamma": torch.ones(D), p + "norm2.weight": torch.ones(D), p + "norm2.bias": torch.zeros(D),
+                   p + "mlp.fc1.weight": torch.zeros(F, D), p + "mlp.fc1.bias": torch.zeros(F), p + "mlp.fc2.weight": torch.zeros(D, F),
+                   p + "mlp.fc2.bias": torch.zeros(D), p + "ls2.gamma": torch.ones(D)})
+    model = vdr.load_model("dinov2", weights=sd)
+    assert model.model_name == "dinov2" and model.cfg.img == 896 and model.cfg.patch == 14
+    x = torch.rand(1, 3, 896, 896, generator=g)
+    pe = model.patch_embed(x.cuda())                       # tfds_dense_descriptor.py:128
+    assert pe.shape == (1, 4096, D) and pe.dtype == torch.float32
+    ref = torch.nn.functional.conv2d(x.bfloat16().float(), sd["patch_embed.proj.weight"].bfloat16().float(),
+                                     sd["patch_embed.proj.bias"], stride=14).flatten(2).transpose(1, 2)
+    assert _rel_l2(pe.cpu(), ref) < 4e-3
+    f = vdr.get_dense_descriptor(model, x[0].numpy())      # :110-139 -> (64, 64, 384) float32
+    assert f.shape == (64, 64, D) and f.dtype == np.float32
+    np.testing.assert_array_equal(f.reshape(4096, D), pe[0].cpu().numpy())
+    with pytest.raises(vdr.VdrError):                      # there is no CLS path in this mode, as in the reference
+        model.forward_features(x.cuda())
 
 
 def test_full_batch_properties_at_baseline_size():
@@ -527,7 +615,8 @@ def test_golden_reference_bimodal_classifier(golden_dir, tag):
     dim, lc, lp = int(g["dim"]), int(g["layers_ct"]), int(g["layers_pet"])
     rc, rp, hc, hp, ncls = float(g["ratio_ct"]), float(g["ratio_pet"]), int(g["heads_ct"]), int(g["heads_pet"]), int(g["classes"])
     sd = bo.make_state_dict(dim, int(rc * dim), int(rp * dim), lc, lp, ncls, seed=int(g["seed"]))
-    m = vdr.TransformerNoduleBimodalClassifier(dim, rc, rp, hc, hp, lc, lp, ncls, sd)
+    m = vdr.TransformerNoduleBimodalClassifier(dim, rc, rp, hc, hp, lc, lp, ncls)  # reference signature (models_archs.py:39-43)
+    m.load_state_dict(sd)                                                          # models_archs.py:32-35
     x_ct, x_pet = torch.from_numpy(g["x_ct"]).cuda(), torch.from_numpy(g["x_pet"]).cuda()
     L = max(lc, lp) + 1  # encoder depth + the cross-attention / fusion stage
     for mode, (a, b) in (("both", (x_ct, x_pet)), ("ct", (x_ct, None)), ("pet", (None, x_pet))):

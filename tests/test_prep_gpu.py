@@ -67,6 +67,11 @@ def test_window_ct_and_hu_colormap_bit_exact(golden_dir):
     for a, b in (("hu", "rgb"), ("hu_i16", "rgb_i16"), ("hu_f32", "rgb_f32")):
         got = prep.hu_to_rgb_vectorized(h[a]).cpu().numpy()
         assert got.dtype == np.uint8 and np.array_equal(got, h[b]), a
+    # NaN HU: every one of the reference's nine masks is False, the pixel stays at np.zeros' (0, 0, 0)
+    for dt in (np.float32, np.float64):
+        v = np.array([np.nan, 500.0, -2000.0, np.nan], dtype=dt)
+        got = prep.hu_to_rgb_vectorized(v).cpu().numpy()
+        assert np.array_equal(got, np.array([[0, 0, 0], [255, 255, 255], [0, 0, 0], [0, 0, 0]], dtype=np.uint8))
 
 
 def test_crop_maps_matches_reference_roi(golden_dir):
@@ -117,6 +122,40 @@ def test_generate_features_batched_pipeline_vs_oracle():
         rel = np.linalg.norm(feats[i] - want) / np.linalg.norm(want)
         assert rel < 2e-2, (i, rel)
         assert np.array_equal(masks[i], po.extract_roi(mask_c[:, :, i] > 0, big_c))
+
+
+@pytest.mark.parametrize("flip", ["horizontal", "vertical"])
+def test_generate_features_flip_equals_explicitly_flipped_volume(flip):
+    """generate_features(flip=...) == generate_features on flip_image(img, mask) (tfds_dense_descriptor.py:305-324,
+    463-467): the nodule sits off-centre and near a border, so the asymmetric-margin boxes of the flipped mask differ
+    from the mirrored boxes of the unflipped one, and the clamped crop window is not symmetric either."""
+    import vdr
+    from vdr import pipeline, prep
+    from oracle import sam_oracle as so
+    cfg = so.SamCfg(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, window=7, global_idx=(1,), out_chans=64)
+    w = so.make_weights(cfg, seed=23)
+    vc = vdr.VdrConfig(img=224, patch=16, dim=128, heads=2, layers=2, mlp_hidden=256, has_cls=False, window=7,
+                       global_blocks=(1,), neck_chans=64)
+    model = vdr.VitDescriptorModel(vc, w, "medsam", torch.device("cuda"))
+    model.model_name = "medsam"
+    rng = np.random.default_rng(10)
+    H, W, S = 70, 90, 4
+    img = rng.random((H, W, S)).astype(np.float32)
+    mask = np.zeros((H, W, S), dtype=bool)
+    mask[6:19, 60:83, 1:3] = True          # near the top-right corner: the 4 x box window is clamped on two sides
+    mask[9, 58, 2] = True
+    fi, fm = prep.flip_image(img, mask, flip)
+    want_f, want_m = pipeline.generate_features(model, np.ascontiguousarray(fi), np.ascontiguousarray(fm))
+    got_f, got_m = pipeline.generate_features(model, img, mask, flip=flip)
+    assert len(got_f) == len(want_f) == S
+    for i in range(S):
+        assert got_f[i].shape == want_f[i].shape and np.array_equal(got_f[i], want_f[i]), i
+        assert got_m[i].shape == want_m[i].shape and np.array_equal(got_m[i], want_m[i]), i
+    # and it is NOT what the unflipped boxes would give (the bug this guards against)
+    plain_f, plain_m = pipeline.generate_features(model, img, mask)
+    assert any(a.shape != b.shape or not np.array_equal(a, b) for a, b in zip(plain_m, got_m))
+    with pytest.raises(ValueError):
+        pipeline.generate_features(model, img, mask, flip="diagonal")
 
 
 def test_extract_patient_features_augmentation_loop():

@@ -235,9 +235,9 @@ __global__ __launch_bounds__(256) void hu_to_rgb_kernel(const T* __restrict__ hu
     set(a, 102, 0, 0), set(b, 153, 0, 0), mn = 80, mx = 400, mix = true;  // the reference's own bounds for this band
   } else if (v < 400.0) {
     set(a, 153, 0, 0), set(b, 255, 255, 255), mn = 80, mx = 400, mix = true;
-  } else {
+  } else if (v >= 400.0) {
     set(a, 255, 255, 255);
-  }
+  }  // NaN: every comparison of the reference's nine masks is False, the pixel keeps the zeros of np.zeros
   double r1 = 0.0, r0 = 1.0;
   if (mix) {
     if (F32) {

@@ -65,7 +65,6 @@ struct LayerW {
   void* reltab = nullptr;  // both tables packed as one [relpos_npad(S)][64] bf16 GEMM operand
   void *wqkv_f = nullptr, *w1_f = nullptr;
   // fp8 path: MX-fp8 copies (payload, scales) of the qkv / fc1 (w12) / fc2 (w3) weights
-  void *proj_q = nullptr, *proj_s = nullptr;
   void *qkv_q = nullptr, *qkv_s = nullptr, *w1_q = nullptr, *w1_s = nullptr, *w2_q = nullptr, *w2_s = nullptr;
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
@@ -226,7 +225,7 @@ int env_int(const char* name, int dflt) {
 
 bool ln_fusion_wanted(const vdr_model* m) {
   const vdr_config& c = m->cfg;
-  if (env_int("VDR_LN_FUSE", 1) == 0) return false;
+  if (c.no_ln_fold || env_int("VDR_LN_FUSE", 1) == 0) return false;
   return c.patch && c.pre_ln && !c.input_ln && !c.fp8 && (c.dim % 64) == 0;
 }
 
@@ -348,7 +347,6 @@ int resolve(vdr_model* m) {
       LayerW& L = m->layers[i];
       int rc;
       if ((rc = quant(L.wqkv, 3 * D, D, &L.qkv_q, &L.qkv_s))) return rc;
-      if ((rc = quant(L.wproj, D, D, &L.proj_q, &L.proj_s))) return rc;
       if ((rc = quant(L.w1, N1, D, &L.w1_q, &L.w1_s))) return rc;
       if ((rc = quant(L.w2, D, F, &L.w2_q, &L.w2_s))) return rc;
     }
@@ -386,7 +384,7 @@ int resolve(vdr_model* m) {
       if ((rc = pack(L.w1, N1, D)) || (rc = pack(L.w1_f, N1, D))) return rc;
       if ((rc = pack(L.w2, D, F))) return rc;
     }
-    if (c.fp8 == 1)  // the out-projection stays bf16 at fp8 level 1
+    if (c.fp8)  // the out-projection stays bf16 on the fp8 path
       for (int i = 0; i < c.layers; ++i)
         if ((rc = pack(m->layers[i].wproj, D, D))) return rc;
     if (c.window > 0) {
@@ -716,7 +714,6 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
     // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
     // operands); the residual stream and the attention arithmetic stay bf16 / fp32.
     const int N1 = sw ? 2 * F : F;
-    const bool proj_mx = c.fp8 >= 2;  // fp8 = 1: qkv / fc1 / fc2; fp8 = 2: the out-projection (and the attention output) too
     for (int i = 0; i < c.layers; ++i) {
       const LayerW& L = m->layers[i];
       {
@@ -729,15 +726,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
-        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, proj_mx ? w.os : nullptr, lens, len_add), "attention");
+        VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
-      if (proj_mx) {
-        if ((rc = gemm_mx(m, s, VDR_K_GEMM_PROJ, w.o, w.os, L.proj_q, L.proj_s, L.bproj, w.x, L.ls1, w.x, nullptr, M, D, D, D,
-                          EPI_BIAS_RESID)))
-          return rc;
-      } else if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) {
-        return rc;
-      }
+      // the out-projection stays bf16: quantising it too measured 0.987 row cosine at 40 blocks (gate 0.99)
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
       {
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
@@ -1040,6 +1032,10 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
   }
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
   if (c.fp8 && !c.pre_ln) return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models only");
+  if (c.fp8 < 0 || c.fp8 > 1)
+    return fail(nullptr, VDR_ERR_UNSUPPORTED,
+                "fp8 must be 0 or 1 (a level that also quantised the out-projection measured 0.987 row cosine at 40 "
+                "blocks, below the 0.99 gate, and is not shipped)");
   if (c.window > 0) {
     const int g = c.patch ? c.img / c.patch : 0;
     auto side_ok = [](int v) { return v == 4 || v == 7 || v == 10 || v == 14 || v == 64; };
@@ -1078,7 +1074,7 @@ void vdr_destroy(vdr_handle h) {
   for (auto& L : h->layers) {
     if (L.wqkv_f) hipFree(L.wqkv_f);
     if (L.reltab) hipFree(L.reltab);
-    for (void* q : {L.qkv_q, L.qkv_s, L.proj_q, L.proj_s, L.w1_q, L.w1_s, L.w2_q, L.w2_s})
+    for (void* q : {L.qkv_q, L.qkv_s, L.w1_q, L.w1_s, L.w2_q, L.w2_s})
       if (q) hipFree(q);
     if (L.w1_f) hipFree(L.w1_f);
     if (L.sqkv) hipFree(L.sqkv);

@@ -27,7 +27,7 @@ class vdr_config(C.Structure):
                 ("pre_ln", C.c_int32), ("layerscale", C.c_int32), ("has_cls", C.c_int32), ("has_pos", C.c_int32),
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
                 ("streams", C.c_int32), ("window", C.c_int32),
-                ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32)]
+                ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)

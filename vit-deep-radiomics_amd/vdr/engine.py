@@ -33,7 +33,8 @@ class VdrConfig:
     window: int = 0            # SAM: windowed attention side (14) + decomposed rel-pos
     global_blocks: tuple = ()  # SAM: blocks with global attention (2, 5, 8, 11)
     neck_chans: int = 0        # SAM: conv neck output channels (256)
-    fp8: int = 0               # 1: qkv / fc1 / fc2 as MX-fp8 (BASELINE config 5); 2: the out-projection too
+    fp8: int = 0               # 1: qkv / fc1 / fc2 as MX-fp8 (BASELINE config 5)
+    ln_fold: bool = True       # pre-LN image models: LayerNorm folded into the qkv / fc1 GEMMs (False: explicit kernel)
 
     @property
     def n_patches(self):
@@ -54,6 +55,7 @@ class VdrConfig:
         c.window, c.neck_chans = int(self.window), int(self.neck_chans)
         c.global_mask = sum(1 << int(i) for i in self.global_blocks)
         c.fp8 = int(self.fp8)
+        c.no_ln_fold = int(not self.ln_fold)
         return c
 
 
@@ -146,8 +148,24 @@ class Engine:
         return out
 
     def forward_into(self, images: torch.Tensor, out: torch.Tensor, out_mode: int = L.OUT_CLS):
-        """As forward(), writing into a caller-owned buffer (e.g. this rank's slice of the all-gather buffer)."""
+        """As forward(), writing into a caller-owned buffer (e.g. this rank's slice of the all-gather buffer).
+        Nothing is converted or copied here, so everything is checked: a wrong dtype / layout / size is an error, never
+        an out-of-bounds write."""
+        cfg = self.cfg
+        if images.dim() != 4 or tuple(images.shape[1:]) != (cfg.in_chans, cfg.img, cfg.img):
+            raise ValueError(f"images must be [B,{cfg.in_chans},{cfg.img},{cfg.img}], got {tuple(images.shape)}")
+        if images.dtype not in _DT or out.dtype not in _DT:
+            raise TypeError(f"images / out must be float32 or bfloat16, got {images.dtype} / {out.dtype}")
+        if images.device != self.device or out.device != self.device:
+            raise ValueError(f"images and out must live on {self.device}")
+        if not images.is_contiguous() or not out.is_contiguous():
+            raise ValueError("images and out must be contiguous")
         B = images.shape[0]
+        g = cfg.img // cfg.patch
+        per_image = {L.OUT_CLS: cfg.dim, L.OUT_DENSE: cfg.n_patches * cfg.dim, L.OUT_PATCH_EMBED: cfg.n_patches * cfg.dim,
+                     L.OUT_TOKENS: cfg.n_tokens * cfg.dim, L.OUT_ENCODER: g * g * cfg.neck_chans}[out_mode]
+        if out.numel() != B * per_image:
+            raise ValueError(f"out has {out.numel()} elements, the forward writes {B} x {per_image}")
         ws = self._workspace(B)
         L.check(self.lib.vdr_forward(self.h, images.data_ptr(), _DT[images.dtype], B, out.data_ptr(), out_mode,
                                      _DT[out.dtype], ws.data_ptr(), ws.numel(), _stream_ptr(self.device)), self.h)

@@ -22,8 +22,14 @@ ARCHS = {
     "vit_base16_224": VdrConfig(224, 16, 3, 768, 12, 12, 3072),
     "vit_large14_336": VdrConfig(336, 14, 3, 1024, 16, 24, 4096),
     "dinov2_giant14_224": VdrConfig(224, 14, 3, 1536, 24, 40, 4096, act="swiglu", layerscale=True),
-    # reference default for model_name='dinov2' (load_dinov2('small'), run at 896x896)
-    "dinov2": VdrConfig(896, 14, 3, 384, 6, 12, 1536, layerscale=True),
+    # reference default for model_name='dinov2': load_dinov2('small') = dinov2_vits14, of which the hot loop runs
+    # `model.patch_embed(x)` ONLY, at 896x896 (tfds_dense_descriptor.py:128-133).  So the drop-in for that name is the
+    # patch embedding alone: no blocks, no cls / pos / norm -- a real dinov2_vits14 state_dict loads as it is (its
+    # pos_embed is [1, 1370, 384] for 518^2 and would need DINOv2's run-time interpolation for any other use; its
+    # cls_token / mask_token / blocks.* / norm.* keys are ignored here exactly as the reference ignores them).
+    "dinov2": VdrConfig(896, 14, 3, 384, 6, 0, 1536, pre_ln=False, has_cls=False, has_pos=False),
+    # the whole ViT-S/14 at 896^2 (pos_embed must already be [1, 4097, 384])
+    "dinov2_small14_896": VdrConfig(896, 14, 3, 384, 6, 12, 1536, layerscale=True),
     # reference default backbone: sam_model_registry['vit_b'] image encoder (MedSAM checkpoint), 1024x1024
     "medsam": VdrConfig(1024, 16, 3, 768, 12, 12, 3072, has_cls=False, window=14, global_blocks=(2, 5, 8, 11),
                         neck_chans=256),
@@ -134,32 +140,11 @@ def extract_dense(model, images: torch.Tensor, encoder: bool = True) -> np.ndarr
     return f.reshape(images.shape[0], g, g, model.cfg.dim).cpu().numpy()
 
 
-class TransformerNoduleClassifier:
-    """R3: drop-in for models_archs.TransformerNoduleClassifier in eval mode.
-    model(x[B,S,D]) -> (logits [B,C], cls [B,D])."""
+class _DropIn:
+    """nn.Module-style surface the reference's checkpoint helpers use (models_archs.py:14-35: `model.state_dict()`,
+    `model.load_state_dict(torch.load(path))`, `model.to(device)`, `model.eval()`)."""
 
-    def __init__(self, input_dim, dim_feedforward, num_heads, num_classes, num_layers, state_dict, device=None):
-        from .weights import from_torch_encoder_state_dict
-        cfg = VdrConfig(img=0, patch=0, in_chans=0, dim=input_dim, heads=num_heads, layers=num_layers,
-                        mlp_hidden=dim_feedforward, act="gelu", pre_ln=False, layerscale=False, has_cls=True,
-                        has_pos=False, input_ln=True, ln_eps=1e-5)
-        self.cfg = cfg
-        self.engine = Engine(cfg, device)
-        self.engine.load_weights(from_torch_encoder_state_dict(state_dict, num_layers))
-        dev = self.engine.device
-        sd = state_dict
-        self.num_classes = num_classes
-        # MLPLayer head (models_archs.py:186-200): dense1 -> GELU -> dense2, through vdr_op_linear;
-        # dense2's num_classes rows are zero-padded to 8 for the GEMM's N % 8 == 0 rule.
-        self.w1 = sd["classifier.dense1.weight"].to(dev, torch.bfloat16).contiguous()
-        self.b1 = sd["classifier.dense1.bias"].to(dev, torch.float32).contiguous()
-        npad = (num_classes + 7) // 8 * 8
-        w2 = torch.zeros((npad, self.w1.shape[0]), dtype=torch.float32)
-        w2[:num_classes] = sd["classifier.dense2.weight"].float().cpu()
-        b2 = torch.zeros((npad,), dtype=torch.float32)
-        b2[:num_classes] = sd["classifier.dense2.bias"].float().cpu()
-        self.w2 = w2.to(dev, torch.bfloat16).contiguous()
-        self.b2 = b2.to(dev)
+    _sd = None
 
     def eval(self):
         return self
@@ -167,18 +152,57 @@ class TransformerNoduleClassifier:
     def to(self, *a, **k):
         return self
 
+    def cuda(self, device=None):
+        return self
+
+    def state_dict(self):
+        self._need_weights()
+        return dict(self._sd)
+
+    def _need_weights(self):
+        if self._sd is None:
+            raise RuntimeError(f"{type(self).__name__}: no weights yet — call load_state_dict(state_dict) first "
+                               "(the reference's load(), models_archs.py:32-35)")
+
+
+class TransformerNoduleClassifier(_DropIn):
+    """R3: drop-in for models_archs.TransformerNoduleClassifier in eval mode: the reference's constructor signature
+    (models_archs.py:128), then `load_state_dict(sd)` as models_archs.load does (:32-35); `state_dict=` in the
+    constructor is a shortcut for the two steps.  model(x[B,S,D]) -> (logits [B,C], cls [B,D])."""
+
+    def __init__(self, input_dim, dim_feedforward, num_heads, num_classes, num_layers, state_dict=None, device=None):
+        self.cfg = VdrConfig(img=0, patch=0, in_chans=0, dim=input_dim, heads=num_heads, layers=num_layers,
+                             mlp_hidden=dim_feedforward, act="gelu", pre_ln=False, layerscale=False, has_cls=True,
+                             has_pos=False, input_ln=True, ln_eps=1e-5)
+        self.num_classes, self.num_layers = num_classes, num_layers
+        self.engine = Engine(self.cfg, device)
+        self.device = self.engine.device
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """state_dict with the reference class's key names (cls_token, norm.*, transformer_encoder.layers.{i}.*,
+        classifier.dense1/2.*)."""
+        from .weights import from_torch_encoder_state_dict
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        self.engine.load_weights(from_torch_encoder_state_dict(sd, self.num_layers), strict=strict)
+        # MLPLayer head (models_archs.py:186-200): dense1 -> GELU -> dense2, through vdr_op_linear
+        self.head = _MlpHead(sd, "classifier", self.device)
+        if self.head.n != self.num_classes:
+            raise ValueError(f"classifier.dense2 has {self.head.n} rows, model was built for {self.num_classes} classes")
+        self._sd = sd
+        return self
+
     def __call__(self, x, lengths=None):
         """x [B,S,D] -> (logits, cls) as the reference.  Variable-length batches (the reference runs batch_size 1
         because its masked-voxel sequences differ in length): pass x padded to the longest sequence plus
         `lengths` [B], or a list of [S_i, D] tensors (padded here)."""
-        from . import ops
+        self._need_weights()
         if isinstance(x, (list, tuple)):
             lengths = [int(t.shape[0]) for t in x]
             x = torch.nn.utils.rnn.pad_sequence([torch.as_tensor(t).float() for t in x], batch_first=True)
         cls = self.engine.forward_tokens(x, L.OUT_CLS, torch.float32, lengths=lengths)
-        hid = ops.linear(cls.to(torch.bfloat16), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
-        logits = ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.num_classes].float()
-        return logits, cls
+        return self.head(cls), cls
 
 
 class _MlpHead:
@@ -234,41 +258,44 @@ class _CrossAttentionCls:
         return ops.linear(o, self.wo, self.bo).float()
 
 
-class TransformerNoduleBimodalClassifier:
-    """Drop-in for models_archs.TransformerNoduleBimodalClassifier (:38-124) in eval mode: same constructor
-    arguments plus the state_dict (reference key names), `model(x_ct, x_pet)` ->
-    (logits_petct, petct_cls_token, logits_ct, logits_pet); either modality may be None, as in the reference."""
+class TransformerNoduleBimodalClassifier(_DropIn):
+    """Drop-in for models_archs.TransformerNoduleBimodalClassifier (:38-124) in eval mode: the reference's constructor
+    arguments, then `load_state_dict(sd)` (reference key names; `state_dict=` in the constructor is a shortcut);
+    `model(x_ct, x_pet)` -> (logits_petct, petct_cls_token, logits_ct, logits_pet); either modality may be None, as in
+    the reference."""
 
     def __init__(self, input_dim, mlp_ratio_ct, mlp_ratio_pet, num_heads_ct, num_heads_pet, num_layers_ct, num_layers_pet,
-                 num_classes, state_dict, device=None):
-        from .weights import from_torch_encoder_state_dict
-        sd = state_dict
-        self.engines = {}
+                 num_classes, state_dict=None, device=None):
+        self.engines, self._layers = {}, {}
         for m, ratio, heads, layers in (("ct", mlp_ratio_ct, num_heads_ct, num_layers_ct),
                                         ("pet", mlp_ratio_pet, num_heads_pet, num_layers_pet)):
             cfg = VdrConfig(img=0, patch=0, in_chans=0, dim=input_dim, heads=heads, layers=layers,
                             mlp_hidden=int(ratio * input_dim), act="gelu", pre_ln=False, layerscale=False, has_cls=True,
                             has_pos=False, input_ln=True, ln_eps=1e-5)
-            eng = Engine(cfg, device)
+            self.engines[m] = Engine(cfg, device)
+            self._layers[m] = layers
+        self.device = self.engines["ct"].device
+        self.num_classes = num_classes
+        self._cross_heads = num_heads_ct  # the reference constructs BOTH cross-attention layers with num_heads_ct (:71-72)
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    def load_state_dict(self, state_dict, strict=True):
+        from .weights import from_torch_encoder_state_dict
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        for m, eng in self.engines.items():
             sub = {"cls_token": sd[f"cls_token_{m}"], "norm.weight": sd[f"norm_{m}.weight"], "norm.bias": sd[f"norm_{m}.bias"]}
             pre = f"transformer_encoder_{m}."
             sub.update({"transformer_encoder." + k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
-            eng.load_weights(from_torch_encoder_state_dict(sub, layers))
-            self.engines[m] = eng
-        dev = self.engines["ct"].device
-        self.device = dev
-        self.num_classes = num_classes
-        # the reference constructs BOTH cross-attention layers with num_heads_ct (:71-72)
-        self.cross = {m: _CrossAttentionCls(sd, f"cross_attention_{m}", num_heads_ct, dev) for m in ("ct", "pet")}
+            eng.load_weights(from_torch_encoder_state_dict(sub, self._layers[m]), strict=strict)
+        dev = self.device
+        self.cross = {m: _CrossAttentionCls(sd, f"cross_attention_{m}", self._cross_heads, dev) for m in ("ct", "pet")}
         self.heads = {n: _MlpHead(sd, n, dev) for n in ("classifier_ct", "classifier_pet", "projection_petct", "classifier_petct")}
-
-    def eval(self):
-        return self
-
-    def to(self, *a, **k):
+        self._sd = sd
         return self
 
     def __call__(self, x_ct=None, x_pet=None):
+        self._need_weights()
         if x_ct is None and x_pet is None:
             raise AssertionError("At least one modality should be used")  # the reference's assert
         t = {}

@@ -82,8 +82,20 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
     img_3d  (H, W, S) CT/PET volume in [0, 1] ('medsam') or (H, W, S, 3) ('dinov2'); mask_3d (H, W, S) bool.
     Returns (features_list, mask_list) exactly like the reference: per slice a (h', w', D) float32 array and
     the (h'', w'') bool mask crop.  All S slices go through prepare -> encoder -> ROI crop in batches of
-    `max_batch` on the GPU; one D2H per batch of the already-cropped maps."""
+    `max_batch` on the GPU; one D2H per batch of the already-cropped maps.
+
+    flip ('horizontal' | 'vertical' | None): the result is that of the reference's
+    `generate_features(model, *flip_image(img_3d, mask_3d, flip))` (tfds_dense_descriptor.py:463-467): the mask is
+    flipped first, every box (volume crop, ROI of the feature maps, ROI of the masks -- asymmetric margins and all) is
+    derived from the FLIPPED mask, and the pixels are read from the mirrored window of the unflipped volume with the
+    reversal folded into the resize gather (no flipped copy of the volume is made)."""
+    if flip not in (None, "horizontal", "vertical"):
+        raise ValueError(f"flip must be None, 'horizontal' or 'vertical', got {flip!r}")
     mask_np = mask_3d.cpu().numpy() if isinstance(mask_3d, torch.Tensor) else np.asarray(mask_3d)
+    if flip == "horizontal":
+        mask_np = mask_np[:, ::-1]
+    elif flip == "vertical":
+        mask_np = mask_np[::-1]
     bigger_mask = np.sum(mask_np, axis=-1) > 0
     xmin, ymin, xmax, ymax = extract_coords(bigger_mask, margin=2)
     crop_size = max(xmax - xmin, ymax - ymin) * 2
@@ -91,8 +103,13 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
     box = (xmid - crop_size, ymid - crop_size, xmid + crop_size, ymid + crop_size)
 
     vol = torch.as_tensor(img_3d)
-    y0, y1, x0, x1 = crop_box(vol.shape[0:2], *box)
-    vol = vol[y0:y1, x0:x1]                      # a view; prepare_slices reads it strided
+    y0, y1, x0, x1 = crop_box(vol.shape[0:2], *box)   # in the coordinates of the flipped volume
+    vy0, vy1, vx0, vx1 = y0, y1, x0, x1              # the same window in the unflipped volume: mirrored
+    if flip == "horizontal":
+        vx0, vx1 = vol.shape[1] - x1, vol.shape[1] - x0
+    elif flip == "vertical":
+        vy0, vy1 = vol.shape[0] - y1, vol.shape[0] - y0
+    vol = vol[vy0:vy1, vx0:vx1]                  # a view; prepare_slices reads it strided (and reversed, for a flip)
     mask_c = mask_np[y0:y1, x0:x1]
     bigger_c = bigger_mask[y0:y1, x0:x1]
     vol = vol.to(model.device)
@@ -128,19 +145,7 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
 
 
 # ---- tfds_dense_descriptor.py:142-165 -----------------------------------------------------------------------
-def save_features(filename, all_features, all_masks, patient_id):
-    """HDF5 layout of the reference: group `patient_id`, datasets `features/{i}` and `masks/{i}`, lzf, one chunk."""
-    try:
-        import h5py
-    except ImportError as e:  # not installed in every image; nothing else can write this format
-        raise RuntimeError("save_features needs h5py (the reference's on-disk format is HDF5)") from e
-    with h5py.File(filename, "a") as h5f:
-        if patient_id in h5f:
-            del h5f[patient_id]
-        grp = h5f.create_group(patient_id)
-        for i, (feature, mask) in enumerate(zip(all_features, all_masks)):
-            grp.create_dataset(f"features/{i}", compression="lzf", data=feature, chunks=feature.shape)
-            grp.create_dataset(f"masks/{i}", compression="lzf", data=mask, chunks=mask.shape)
+from .h5store import read_features, save_features  # noqa: E402,F401  (torch-free module: also runs where only h5py is)
 
 
 # ---- tfds_dense_descriptor.py:452-491 ------------------------------------------------------------------------
@@ -199,6 +204,12 @@ def extract_patient_features(model, img_raw, mask_raw, patient_id, label, datase
     all_features, all_masks, counts, augs = [], [], [], []
     img = torch.as_tensor(np.asarray(img_raw) if not isinstance(img_raw, torch.Tensor) else img_raw)
     if img.dtype not in (torch.float32, torch.float64):
+        # scipy.ndimage.rotate on an INTEGER volume rounds its result back to the integer dtype; that store is not
+        # restated on the GPU (prep.rotate_volume refuses integers), and the reference's volumes are floats at this
+        # point (apply_window_ct / PET SUV): refuse rather than rotate something SciPy would round differently
+        if any(a != 0 for a in angles):
+            raise TypeError(f"extract_patient_features rotates float32 / float64 volumes only, got {img.dtype}; "
+                            "convert explicitly (the reference passes windowed CT / PET floats)")
         img = img.to(torch.float64)
     img = img.to(model.device)
     mask = torch.as_tensor(np.asarray(mask_raw) if not isinstance(mask_raw, torch.Tensor) else mask_raw).to(model.device)

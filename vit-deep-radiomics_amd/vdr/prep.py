@@ -66,7 +66,9 @@ def prepare_image(img, device=None) -> torch.Tensor:
 
 
 def apply_window_ct(ct, width, level, device=None) -> torch.Tensor:
-    """HU volume (float32 or int16) -> float32 device tensor in [0, 1]."""
+    """HU volume (float32 or int16) -> float32 device tensor in [0, 1], bit-identical to the reference's numpy result
+    for those dtypes.  A float64 volume is rounded to float32 FIRST (numpy would window in float64 and return float64):
+    the only consumer, prepare_image, casts to float32 anyway; pass float32 when the last ulp has to match."""
     lib = L.load()
     t = _dev(ct, device, (torch.float32, torch.int16)).contiguous()
     out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
