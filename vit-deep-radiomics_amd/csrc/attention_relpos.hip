@@ -248,18 +248,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
-    if (q < p.seq) {
-      bf16_t* dst = ob + (int64_t)q * p.ld_out;
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[nd][4 * g + e] * inv);
-          *reinterpret_cast<bf16x4*>(dst + nd * 32 + 8 * g + 4 * hh) = v;
-        }
-    }
+    store_row64_bf16(ob + (int64_t)(q < p.seq ? q : 0) * p.ld_out, o, inv, hh, q < p.seq);
   };
 
   if (!MULTI) {
@@ -289,9 +278,11 @@ template <int NT, int S, bool MULTI>
 static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
   constexpr size_t lds = (MULTI ? 2 : 1) * 2 * (size_t)NT * 32 * 128;  // (K image + V image) x 1 or 2 buffers
   auto fn = attn_relpos_kernel<NT, S, MULTI>;
-  if (lds > 65536) {
+  static bool attr_set = false;  // per instantiation: raised once, not per launch
+  if (lds > 65536 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    attr_set = true;
   }
   const int nqt = (k.seq + 31) / 32;
   const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));

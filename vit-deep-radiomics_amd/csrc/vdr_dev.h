@@ -53,6 +53,37 @@ VDR_DEV float gelu_erf(float x) {
 
 VDR_DEV float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-x * 1.44269504088896341f)); }
 
+// One output row of the attention kernels (64 head dims, bf16): in the S^T / O^T accumulator layout lane (row, hh) holds
+// dims nd*32 + 8g + 4hh + e (e = 0..3) and its partner lane (xor 32) the other 4 of every 8.  One v_permlane32_swap per
+// dword gives the lower lane dims 8g .. 8g+7 and the upper lane 8(g+1) .. 8(g+1)+7 of each group pair: 4 stores of
+// 16 B per lane instead of 8 of 8 B (a store instruction costs the same issue slot whatever its width).  Every lane
+// must execute this (cross-lane exchange); `ok` only gates the stores.
+VDR_DEV void store_row64_bf16(bf16_t* dst, const f32x16 (&o)[2], float inv, int hh, bool ok) {
+#pragma unroll
+  for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      uint32_t a[2], b[2];  // a: group 2gp, b: group 2gp+1, each 4 bf16 = 2 dwords
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        bf16x2 va, vb;
+        va[0] = (bf16_t)(o[nd][8 * gp + 2 * d] * inv);
+        va[1] = (bf16_t)(o[nd][8 * gp + 2 * d + 1] * inv);
+        vb[0] = (bf16_t)(o[nd][8 * gp + 4 + 2 * d] * inv);
+        vb[1] = (bf16_t)(o[nd][8 * gp + 4 + 2 * d + 1] * inv);
+        const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, va), __builtin_bit_cast(uint32_t, vb), false, false);
+        a[d] = r[0];
+        b[d] = r[1];
+      }
+      u32x4 v;
+      v[0] = a[0];
+      v[1] = a[1];
+      v[2] = b[0];
+      v[3] = b[1];
+      if (ok) *reinterpret_cast<u32x4*>(dst + nd * 32 + 8 * (2 * gp + hh)) = v;
+    }
+}
+
 // XCD-aware bijective remap of a 1-D workgroup id: workgroups that share an XCD (id % 8) get a
 // contiguous range of logical ids, so neighbouring tiles hit the same private L2.
 VDR_DEV int xcd_remap(int id, int nwg) {
