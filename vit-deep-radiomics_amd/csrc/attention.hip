@@ -302,8 +302,13 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
       }
     }
   };
-  auto stage_write = [&](char*) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // own K / V pieces landed, own LDS reads done
+  // end of an item: this wave's K / V pieces of the NEXT item have landed and its LDS reads of the current one are
+  // done.  A computing wave already waited for its pieces (and the next Q) right before its output stores -- they had
+  // the whole tile's compute time to land -- so that the stores themselves stay in flight across the barrier instead
+  // of every wave sitting out their acknowledgement once per item.
+  auto stage_write = [&](bool waited_before_stores) {
+    if (waited_before_stores) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   };
 
   // Q fragments of this wave's query tile (B operand of S^T = K.Q^T): 4 x 16 B straight from global
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next item's K / V pieces and Q (issued long ago); see stage_write
     attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
   };
 
@@ -435,15 +441,16 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
   bf16x8 qf[4];
   stage_issue(item, smem);
   if (computes) load_q(item, wave, qf);
-  stage_write(smem);
+  stage_write(false);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));  // retired by the vmcnt(0) just above
   int cur = 0;
-  for (; item < n_items; item += gridDim.x) {
+  const int stride = __builtin_amdgcn_readfirstlane(gridDim.x);  // (kept in an SGPR: the memory clobbers below would re-read it)
+  for (; item < n_items; item += stride) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // buffer `cur` holds this item; the other buffer is free
     asm volatile("" ::: "memory");
-    const int next = item + gridDim.x;
+    const int next = item + stride;
 #ifdef VDR_TUNING
     const bool more = next < n_items && !(p.abl & 2);
     const bool do_compute = !(p.abl & 1);
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
 #endif
     if (more) stage_issue(next, smem + (cur ^ 1) * BUF);
     if (computes && do_compute) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
-    if (more) stage_write(smem + (cur ^ 1) * BUF);
+    if (more) stage_write(computes && do_compute);
     // The next item's Q fragments were fetched by ordinary loads during compute_tile.  Retire them
     // HERE (they have long landed): otherwise hipcc, which cannot count past the LDS-DMA issued at the
     // top of the next item, would wait vmcnt(0) at their first use and expose the whole staging latency.
