@@ -1,15 +1,23 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summaries for the three benchmark lines recorded under profiles/ (run on the GPU box)
+# rocprofv3 kernel-trace summaries for the benchmark lines recorded under profiles/ (run on the GPU box):
+#   bash tools/prof_round.sh [names...]   default: all
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/prof
 run() {  # name, bench args...
   name=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- python3 bench.py "$@" --no-cpu-baseline > gpurun_out/prof_$name.json.log 2>&1
-  f=$(find gpurun_out/prof_$name -name "*kernel_stats.csv" | head -1)
-  if [ -n "$f" ]; then cp "$f" gpurun_out/prof_${name}_kernel_stats.csv; fi
-  tail -1 gpurun_out/prof_$name.json.log | cut -c1-200
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/$name -- python3 bench.py "$@" --no-cpu-baseline > gpurun_out/prof/$name.json.log 2>&1
+  f=$(find gpurun_out/prof/$name -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then cp "$f" gpurun_out/prof/${name}_kernel_stats.csv; fi
+  rm -rf gpurun_out/prof/$name
+  tail -1 gpurun_out/prof/$name.json.log | cut -c1-200
 }
-run vitb
-run medsam_b1 --model medsam --batch 1
-run vitg_fp8 --model dinov2_giant14_224 --batch 32 --fp8
-run vitb_fp8 --fp8
+want() { [ $# -eq 0 ] && return 0; for n in "$@"; do [ "$n" = "$NAME" ] && return 0; done; return 1; }
+for spec in "vitb" "medsam_b1 --model medsam --batch 1" "medsam_b16 --model medsam --batch 16 --steps 10" \
+            "vitl_dense --model vit_large14_336 --batch 64 --out dense --steps 10" \
+            "vitg_fp8 --model dinov2_giant14_224 --batch 32 --fp8 --steps 10" "vitg_bf16 --model dinov2_giant14_224 --batch 32 --steps 10"; do
+  set -- $spec_args
+  NAME=${spec%% *}
+  ARGS=${spec#"$NAME"}
+  if [ -z "$WANT" ] || echo " $WANT " | grep -q " $NAME "; then run $NAME $ARGS; fi
+done

@@ -39,7 +39,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   g_gemm_ablation = variant / 100;  // tools/: 1xx no epilogue, 4xx no global loads after the ring fill, 8xx no stores
   variant %= 100;
 #endif
-  if (a.out_f32 && epilogue != EPI_BIAS) return hipErrorInvalidValue;
+  if (a.out_f32 && epilogue != EPI_BIAS && epilogue != EPI_PATCH) return hipErrorInvalidValue;
   if (a.ln_part && (a.N & 63)) return hipErrorInvalidValue;
   switch (variant) {
     case 22:
