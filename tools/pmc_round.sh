@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes over the default bench (one counter group per pass, no trace domains), summarised into
-# profiles/r01_pmc_traffic.{txt,json} by tools/pmc_summarize.py.  Run on the GPU box:  tools/pmc_round.sh
+# profiles/rNN_pmc_traffic.{txt,json} by tools/pmc_summarize.py.  Run on the GPU box:  tools/pmc_round.sh
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pass() {  # name, counters...
@@ -13,4 +13,6 @@ pass() {  # name, counters...
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
-python3 tools/pmc_summarize.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv gpurun_out/pmc_sq.csv gpurun_out/pmc_summary
+pass sq2 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+python3 tools/pmc_summarize.py gpurun_out/pmc_fetch.csv gpurun_out/pmc_write.csv gpurun_out/pmc_sq.csv gpurun_out/pmc_summary gpurun_out/pmc_sq2.csv
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/pmc_sq2

@@ -545,11 +545,12 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) {
     static const int small = env_int("VDR_GEMM_VARIANT_SMALL", -1);
     if (small >= 0) return small;
-    // ring3 128x128 tiles.  Variant 25 (the K loop split across two wave groups of the workgroup) is 2 % faster on a
-    // MedSAM batch-1 forward (fc2 at M = 4096 42.7 -> 37.6 us) but sums K in a different order than the big-batch
-    // kernels, so a row would no longer be bitwise independent of the batch it is in: opt-in only
+    // ring4 128x128 tiles (variant 28).  Measured at M = 4096 / 4900 (one MedSAM slice), interleaved rounds: against
+    // ring3 128x128 (24) proj 18.8 -> 17.7 us, fc2 43.9 -> 41.0 us.  Variant 25 (the K loop split across two wave groups
+    // of the workgroup) is faster still (16.5 / 37.1 us) but sums K in a different order than the big-batch kernels,
+    // so a row would no longer be bitwise independent of the batch it travels in: tuning builds only
     // (VDR_GEMM_VARIANT_SMALL=25), the default keeps rows batch-invariant.
-    return 24;
+    return 28;
   }
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
