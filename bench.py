@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--input", choices=["bf16", "fp32"], default="bf16",
                     help="dtype of the resident input images (the reference feeds fp32; SURVEY §8d asks for both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-stream", action="store_true",
+                    help="skip the extra (untimed-region) pass that measures the same step with micro-batches of B/2 on two "
+                         "internal HIP streams (reported as `two_stream`; never the headline value)")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
     a = ap.parse_args()
@@ -221,6 +224,29 @@ def main():
         v["bytes"] /= a.steps
         v["launches"] = v["launches"] / a.steps
 
+    # informational: the same K steps with the batch split over two internal HIP streams (vdr_config.streams = 2,
+    # micro_batch = B/2).  Kernels of the two halves overlap (one GEMM's store-heavy epilogue and ramp-down under the
+    # other's main loop), so the step gets shorter while every single launch gets LONGER -- which is why it is not the
+    # default configuration of the measurement: the per-kernel roofline above is taken with one kernel on the chip.
+    two = None
+    if not a.no_two_stream and not sam and world == 1 and B >= 2 and not a.streams and not a.micro_batch:
+        try:
+            m2 = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=(B + 1) // 2, streams=2, fp8=a.fp8)
+            mode = vdr.OUT_DENSE if dense else vdr.OUT_CLS
+            for _ in range(max(a.warmup, 2)):
+                m2.engine.forward_into(images, mine, mode)
+            sync()
+            t2 = time.perf_counter()
+            for _ in range(a.steps):
+                m2.engine.forward_into(images, mine, mode)
+            sync()
+            dt2 = time.perf_counter() - t2
+            two = {"value": round(B * a.steps / dt2, 1), "ms_per_step": round(dt2 / a.steps * 1e3, 3), "micro_batch": (B + 1) // 2,
+                   "streams": 2}
+            del m2
+        except Exception as e:  # never let the side measurement break the benchmark line
+            two = {"error": str(e)[:200]}
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +301,7 @@ def main():
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
-               "roofline": roof, "kernels": kern}
+               "roofline": roof, "kernels": kern, "two_stream": two}
         if not a.no_cpu_baseline and world == 1 and not sam:
             out["cpu_baseline"] = cpu_baseline(a.model)
         print(json.dumps(out), flush=True)

@@ -17,7 +17,7 @@ d = json.loads(line)
 print(f"# Per-kernel roofline, {d['config']['workload']}")
 print(f"\n`{d['metric']}`: **{d['value']} {d['unit']}**, {d['ms_per_step']} ms/step, n_gpus {d['n_gpus']}; "
       f"dominant kernel `{d['roofline']['kernel']}` {d['roofline']['achieved']} TFLOP/s = {d['roofline']['frac']} of {d['roofline']['peak']}.")
-print("\nTimes: HIP events recorded by libvdr on the stream of each launch (one fully bracketed step); work: algorithmic FLOPs /")
+print("\nTimes: HIP events recorded by libvdr on the stream of each launch, averaged over the bench's K steps (second, fully bracketed pass); work: algorithmic FLOPs /")
 print("bytes of DESIGN.md §4.  MFMA-bound classes are priced against 2.5 PFLOP/s dense bf16, HBM-bound ones against 8 TB/s.\n")
 print("| kernel class | what | launches/step | ms/step | share | achieved | bound | fraction of peak |")
 print("|---|---|---|---|---|---|---|---|")

@@ -36,6 +36,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
   if (a.K <= 0 || (a.K & 63) || (a.N & 7) || a.M <= 0) return hipErrorInvalidValue;
   if (epilogue == EPI_SWIGLU && (a.N & 63)) return hipErrorInvalidValue;
 #ifdef VDR_TUNING
+  g_gemm_gn = variant >= 1000 ? variant / 1000 - 1 : -1;  // tools/: (gn + 1) * 1000 + v forces the column-group width gn
+  variant %= 1000;
   g_gemm_ablation = variant / 100;  // tools/: 1xx no epilogue, 4xx no global loads after the ring fill, 8xx no stores
   variant %= 100;
 #endif

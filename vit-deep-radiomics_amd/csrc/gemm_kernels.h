@@ -602,6 +602,7 @@ static auto launch_pick() -> void (*)(GemmK) {
 }
 
 inline int g_gemm_ablation = 0;  // tuning builds only (variant / 100 of vdr_op_linear)
+inline int g_gemm_gn = -1;       // tuning builds only: column-group width override (variant / 1000 - 1)
 
 // integer tuning knob from the environment: read in tuning builds (-DVDR_TUNING, `make tuning`) only; the shipped
 // library has no environment dependence
@@ -642,14 +643,18 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.tiles_n = (a.N + BN - 1) / BN;
   k.tiles_m = (int)tiles_m;
   {
-    // column-group width: as many W panels (BN x K bf16) as fit in half of an XCD's 4 MB L2, and only when W as a
-    // whole exceeds that L2 (ViT-B: fc1 4.7 MB yes, qkv 3.5 MB no -- measured: fc1 HBM-side reads 790 -> 446 MB and
-    // -2.6 % time, qkv +3 % time).  VDR_GEMM_GN overrides in tuning builds (0 = row-major).
-    static const int gn_env = tuning_env("VDR_GEMM_GN", -1);
-    const size_t panel = (size_t)BN * a.K * 2, whole = (size_t)a.N * a.K * 2;
-    int gn = whole > (4u << 20) ? (int)((2u << 20) / panel) : 0;
-    if (gn < 2) gn = 0;  // a single column at a time re-reads A once per column: never better than row-major
-    k.gn = gn_env >= 0 ? gn_env : gn;
+    // column-group width: tiles are walked in groups of gn tile columns (tile_of) so that a group's W panels (BN x K
+    // bf16 each) stay in the XCD's 4 MB L2 next to the A row panels in flight.  Measured at M = 50432, interleaved
+    // rounds (tools/kbench.py --variants (gn+1)*1000+26): qkv (9 columns, panel 393 KB) 0.192 ms row-major, 0.174 /
+    // 0.171 / 0.175 / 0.176 for gn = 2 / 3 / 4 / 5; fc1 (12 columns) 0.276 row-major, 0.266 / 0.265 / 0.266 for gn = 2 /
+    // 4 / 5, 0.275 for 6: 1.2 - 1.6 MB of W per group (the whole forward, tools/ab_forward.py, same device: 10.54 ms row-major, 10.37 / 10.40 / 10.40 for gn = 3 / 4 / 5).  (Round 1 grouped only when W as a whole exceeded the L2; with
+    // the whole-line operand loads the L2 misses weigh more and qkv gains 10 % too.)  K = 3072 panels (1.6 MB) give
+    // gn = 1: row-major, which is all a 3-column fc2 can use anyway.
+    VDR_KNOB int gn_env = tuning_env("VDR_GEMM_GN", -1);
+    const size_t panel = (size_t)BN * a.K * 2;
+    int gn = (int)((1300u << 10) / panel);
+    if (gn < 2 || gn >= k.tiles_n) gn = 0;  // a single column at a time re-reads A once per column: never better than row-major
+    k.gn = g_gemm_gn >= 0 ? g_gemm_gn : gn_env >= 0 ? gn_env : gn;
   }
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
@@ -661,7 +666,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.a_is = a.a_is;
   k.out_f32 = a.out_f32;
   {
-    static const int nt_env = tuning_env("VDR_GEMM_NT", -1);
+    VDR_KNOB int nt_env = tuning_env("VDR_GEMM_NT", -1);
     const bool big = (double)a.M * (double)a.ldc * 2.0 >= 128e6 && !a.resid;  // write-once output larger than half the Infinity Cache
     k.nt_store = nt_env >= 0 ? nt_env : (big ? 1 : 0);
   }

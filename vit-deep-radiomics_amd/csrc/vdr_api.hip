@@ -538,12 +538,12 @@ struct Scope {
 
 // tile configuration per GEMM class; VDR_GEMM_VARIANT overrides all of them (tuning aid)
 int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
-  static const int forced = env_int("VDR_GEMM_VARIANT", -1);
+  VDR_KNOB int forced = env_int("VDR_GEMM_VARIANT", -1);
   if (forced >= 0) return forced;
   // small problems (a single 1024^2 SAM slice is M = 4096): fewer 128x256 tiles than CUs -> 128x128 tiles
   // (measured, MedSAM batch 1: fc2 0.72 -> 0.57 ms, proj 0.35 -> 0.31 ms per forward)
   if (cls != VDR_K_GEMM_QKV && ((M + 127) / 128) * ((N + 255) / 256) < 256) {
-    static const int small = env_int("VDR_GEMM_VARIANT_SMALL", -1);
+    VDR_KNOB int small = env_int("VDR_GEMM_VARIANT_SMALL", -1);
     if (small >= 0) return small;
     // ring4 128x128 tiles (variant 28).  Measured at M = 4096 / 4900 (one MedSAM slice), interleaved rounds: against
     // ring3 128x128 (24) proj 18.8 -> 17.7 us, fc2 43.9 -> 41.0 us.  Variant 25 (the K loop split across two wave groups
@@ -555,7 +555,7 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   // measured per shape at M = 50432 (tools/kbench.py): 16 waves per CU with 64-register accumulators
   // (wave tile 64x64) beat 8 waves with 128-register accumulators on every shape
   // per-class override for tuning: VDR_GEMM_VARIANT_QKV / _PROJ / _FC1 / _FC2
-  static const int o_qkv = env_int("VDR_GEMM_VARIANT_QKV", -1), o_proj = env_int("VDR_GEMM_VARIANT_PROJ", -1),
+  VDR_KNOB int o_qkv = env_int("VDR_GEMM_VARIANT_QKV", -1), o_proj = env_int("VDR_GEMM_VARIANT_PROJ", -1),
                    o_fc1 = env_int("VDR_GEMM_VARIANT_FC1", -1), o_fc2 = env_int("VDR_GEMM_VARIANT_FC2", -1);
   const int o = cls == VDR_K_GEMM_QKV ? o_qkv : cls == VDR_K_GEMM_PROJ ? o_proj : cls == VDR_K_GEMM_FC1 ? o_fc1
                 : cls == VDR_K_GEMM_FC2 ? o_fc2 : -1;
@@ -586,7 +586,7 @@ struct LnFold {
 // is many (ViT-B batch 256: qkv +3 %, fc1 +4 % against 0.15 ms of ln_finalize launches: 12.15 -> 12.19 ms): taken
 // for launches of at most 2048 tiles.  VDR_LN_IN_GEMM=0 / 1 forces the separate kernel / the in-GEMM form.
 bool ln_stats_in_gemm(int cls, int64_t M, int N, int groups) {
-  static const int mode = env_int("VDR_LN_IN_GEMM", -1);
+  VDR_KNOB int mode = env_int("VDR_LN_IN_GEMM", -1);
   const int v = gemm_variant_for(cls, M, N);
   if (mode == 0 || groups > 16 || v < 22 || v == 25 || v > 28) return false;
   if (mode == 1) return true;
@@ -669,7 +669,7 @@ int layernorm(vdr_model* m, hipStream_t s, int cls, const void* x, int in_bf16, 
 // L transformer blocks over x [M = mb*ntok rows]; leaves the result in w.x
 // tile configuration of the MX-fp8 GEMM per class and shape (VDR_MX_VARIANT overrides)
 int mx_variant_for(int cls, int64_t M, int N) {
-  static const int forced = env_int("VDR_MX_VARIANT", -1);
+  VDR_KNOB int forced = env_int("VDR_MX_VARIANT", -1);
   if (forced >= 0) return forced;
   if (((M + 127) / 128) * ((N + 255) / 256) < 256) return 2;  // small problem: 128x128 tiles
   if (cls == VDR_K_GEMM_QKV) return 0;
@@ -726,7 +726,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
+        VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
       // the out-projection stays bf16: quantising it too measured 0.987 row cosine at 40 blocks (gate 0.99)
@@ -758,7 +758,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-        static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
+        VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
@@ -782,7 +782,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
-      static const int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
+      VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
       VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
     }
     if (c.pre_ln) {

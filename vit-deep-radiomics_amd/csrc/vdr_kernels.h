@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// tuning knobs (-DVDR_TUNING builds read VDR_* environment variables): re-read on every call there, so that one
+// process can alternate settings between forwards (interleaved A/B, tools/ab_forward.py); constants in the shipped build
+#ifdef VDR_TUNING
+#define VDR_KNOB const
+#else
+#define VDR_KNOB static const
+#endif
+
 namespace vdr {
 
 // row r of a compact [R, *] view  <->  row (r / rpg) * gstride + off + (r % rpg) of a token buffer
