@@ -344,7 +344,11 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     for (int ks = 0; ks < 4; ++ks) kch[ks] = ((2 * ks + hh) ^ swz) * 16;
 
     f32x16 s[NT];
-    bf16x8 kf[2];  // K fragments, read one MFMA ahead
+    // K fragments "one MFMA ahead" in the source; hipcc folds the two registers into one and emits ds_read / wait /
+    // v_mfma back to back.  A hand-pipelined form (inline-asm ds_read_b128 two MFMAs ahead, counted lgkmcnt: exactly the
+    // intended ISA, 215 VGPRs) measured the same within the A/B harness's noise (tools/ab_libs.py: 81.2 vs 79.3 us):
+    // with two waves per SIMD the partner's instructions already fill those waits, so the plain form stays.
+    bf16x8 kf[2];
     kf[0] = *reinterpret_cast<const bf16x8*>(sK + kch[0]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
