@@ -3,8 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <type_traits>
-
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -20,32 +18,6 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 VDR_DEV void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (inline-asm immediates need constants)
-template <int I, int N, typename F>
-VDR_DEV void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-// LDS byte address of a pointer into __shared__ memory (the vaddr operand of ds_* instructions)
-VDR_DEV uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
-
-// ds_read_b128 the compiler neither counts nor reorders (cdna_hip_programming.md 5.7, form iii): the caller waits with
-// lds_wait<N>() -- which also fences the MFMAs that consume the data below the wait -- before the first use
-template <int OFF>
-VDR_DEV void lds_read128_async(bf16x8& dst, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-template <int N>
-VDR_DEV void lds_wait() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
 }
 
 VDR_DEV float wave_sum(float v) {
