@@ -25,17 +25,31 @@ def test_expected_weight_shapes_match_oracle_for_every_named_config():
 
 
 def test_torch_encoder_state_dict_translation():
+    """vdr.weights.from_torch_encoder_state_dict (the product's key translation for models_archs.py:127-139 state_dicts)
+    checked against torch itself: a live nn.TransformerEncoder (post-LN, GELU, the reference's construction) with a cls
+    token and an input LayerNorm is run on CPU, its state_dict goes through the PRODUCT's translation, and the oracle's
+    forward on the translated weights must reproduce torch's output -- a swapped q/k/v block, a transposed matrix or a
+    norm1 / norm2 mix-up cannot pass."""
     from vdr.weights import from_torch_encoder_state_dict
-    layer = torch.nn.TransformerEncoderLayer(d_model=64, dim_feedforward=128, nhead=1, activation="gelu", batch_first=True)
-    enc = torch.nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)
+    torch.manual_seed(3)
+    D, H, L, F, B, S = 64, 1, 2, 128, 3, 7
+    layer = torch.nn.TransformerEncoderLayer(d_model=D, dim_feedforward=F, nhead=H, activation="gelu", batch_first=True, dropout=0.0)
+    enc = torch.nn.TransformerEncoder(layer, num_layers=L, enable_nested_tensor=False).eval()
+    norm = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        for p in list(enc.parameters()) + list(norm.parameters()):
+            p.copy_(torch.randn_like(p) * (0.2 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 and p.shape[0] == D else 0.0))
+    cls = torch.randn(1, 1, D)
     sd = {"transformer_encoder." + k: v for k, v in enc.state_dict().items()}
-    sd["cls_token"] = torch.randn(1, 1, 64)
-    sd["norm.weight"], sd["norm.bias"] = torch.ones(64), torch.zeros(64)
-    mine = from_torch_encoder_state_dict(sd, 2)
-    theirs = vo.from_torch_encoder_state_dict(sd, 2)
-    assert sorted(mine) == sorted(theirs) == sorted(vo.weight_shapes(vo.postln_cfg(64, 1, 2, 128)))
-    for k in mine:
-        assert torch.equal(mine[k], theirs[k])
+    sd["cls_token"] = cls
+    sd["norm.weight"], sd["norm.bias"] = norm.weight.detach(), norm.bias.detach()
+    mine = from_torch_encoder_state_dict(sd, L)
+    assert sorted(mine) == sorted(vo.weight_shapes(vo.postln_cfg(D, H, L, F)))
+    x = torch.randn(B, S, D)
+    with torch.no_grad():
+        want = enc(norm(torch.cat([cls.repeat(B, 1, 1), x], dim=1)))[:, 0, :]   # models_archs.py:141-147
+    got = vo.forward_tokens(vo.postln_cfg(D, H, L, F), mine, x)["cls"]
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), float((got - want).abs().max())
 
 
 def test_shard_bounds_cover_rows_in_order():
