@@ -23,10 +23,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--fp8", type=int, default=0)
     a = ap.parse_args()
     assert vdr.load().vdr_tuning_build(), "needs a tuning build: make -C vit-deep-radiomics_amd/csrc TUNING=1"
     cfg = vo.CONFIGS[a.model]
-    model = vdr.load_model(a.model, weights=vo.make_weights(cfg, seed=1))
+    model = vdr.load_model(a.model, weights=vo.make_weights(cfg, seed=1), fp8=a.fp8)
     x = torch.rand(a.batch, 3, cfg.img, cfg.img).to(torch.bfloat16).cuda()
     out = torch.empty(a.batch, cfg.dim, dtype=torch.float32, device="cuda")
     knobs = sorted({kv.split("=")[0] for s in a.settings for kv in s.split() if kv})

@@ -75,8 +75,12 @@ VDR_DEV void gemm_mx_body(const GemmK& p, char* smem) {
     const int c = spc ^ ((r >> 2) & 3);
     int gr = n0 + r;
     gr = gr < p.N ? gr : p.N - 1;
-    b_src[q] = reinterpret_cast<const char*>(p.W) + (int64_t)gr * p.ldw + c * 16;
+    // packed weights (GemmArgs::w_interleaved, gemm_kernels.h): [N/2][K/64][2][64 B] -- a 128-B line holds one 64-element
+    // K unit of rows 2i and 2i+1, so this wave-instruction (16 rows x 64 B) touches 8 whole lines instead of 16 halves
+    b_src[q] = p.w_il ? reinterpret_cast<const char*>(p.W) + (int64_t)(gr >> 1) * ((int64_t)(p.K >> 6) * 128) + (gr & 1) * 64 + c * 16
+                      : reinterpret_cast<const char*>(p.W) + (int64_t)gr * p.ldw + c * 16;
   }
+  const int bstep = p.w_il ? 128 : 64;  // bytes between consecutive units of one W row
   // scale fetch: lanes 0-31 the activation scales, 32-63 the weight scales; 16 lanes per block plane, 4 bytes
   // = two (r, r+32) row pairs each.  Rows past M / N fall inside the 256-row padding of the scale arrays.
   const uint8_t* s_src;
@@ -122,7 +126,7 @@ VDR_DEV void gemm_mx_body(const GemmK& p, char* smem) {
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       glds16(b_src[q], d + BM * 64 + (wave * NB + q) * 1024);
-      b_src[q] += 64;
+      b_src[q] += bstep;
     }
     glds4(s_src, smem + SC + slot * (NW * 256) + wave * 256);
     s_src += s_step;
@@ -214,6 +218,7 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   GemmK k{};
   k.A = (const bf16_t*)a.A;
   k.W = (const bf16_t*)a.W;
+  k.w_il = a.w_interleaved;
   k.bias = a.bias;
   k.resid = (const bf16_t*)a.resid;
   k.gamma = a.gamma;

@@ -343,12 +343,20 @@ int resolve(vdr_model* m) {
       VDR_TRY(launch_mx_quant(wdev, N, K, K, *q, *sc, nullptr), "mx_quant(weight)");
       return VDR_OK;
     };
+    // the e4m3 payloads go to the packed (pair-interleaved) layout too: as bytes, [N][K] fp8 is [N][K/2] bf16, and a
+    // 32-element bf16 block is one 64-element MX unit
+    auto pack8 = [&](void* q, int N, int K) -> int {
+      void*& dst = m->w_il[q];
+      if (!dst) VDR_TRY(hipMalloc(&dst, (size_t)N * K + 256), "hipMalloc(interleaved fp8 weight)");
+      VDR_TRY(launch_w_interleave(q, dst, N, K / 2, K / 2, nullptr), "w_interleave(fp8)");
+      return VDR_OK;
+    };
     for (int i = 0; i < c.layers; ++i) {
       LayerW& L = m->layers[i];
       int rc;
-      if ((rc = quant(L.wqkv, 3 * D, D, &L.qkv_q, &L.qkv_s))) return rc;
-      if ((rc = quant(L.w1, N1, D, &L.w1_q, &L.w1_s))) return rc;
-      if ((rc = quant(L.w2, D, F, &L.w2_q, &L.w2_s))) return rc;
+      if ((rc = quant(L.wqkv, 3 * D, D, &L.qkv_q, &L.qkv_s)) || (rc = pack8(L.qkv_q, 3 * D, D))) return rc;
+      if ((rc = quant(L.w1, N1, D, &L.w1_q, &L.w1_s)) || (rc = pack8(L.w1_q, N1, D))) return rc;
+      if ((rc = quant(L.w2, D, F, &L.w2_q, &L.w2_s)) || (rc = pack8(L.w2_q, D, F))) return rc;
     }
     VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
@@ -700,6 +708,14 @@ int gemm_mx(vdr_model* m, hipStream_t s, int cls, const void* aq, const void* as
   g.omap = identity_map();
   const double outb = cs ? 1.0 : 2.0;
   Scope sc(m, s, cls, 2.0 * M * N * K, (double)M * K + (double)N * K + (double)M * ldc * (resid ? 2 * outb : outb));
+  {
+    VDR_KNOB int packed = env_int("VDR_MX_PACKED", 1);  // (tuning builds: 0 = the row-major payload, for A/B)
+    auto it = m->w_il.find(g.W);
+    if (packed && it != m->w_il.end()) {
+      g.W = it->second;
+      g.w_interleaved = 1;
+    }
+  }
   VDR_TRY(launch_gemm_mx(g, epi, mx_variant_for(cls, M, N), s), "gemm_mx");
   return VDR_OK;
 }
