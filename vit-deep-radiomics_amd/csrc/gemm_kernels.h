@@ -644,15 +644,19 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.tiles_m = (int)tiles_m;
   {
     // column-group width: tiles are walked in groups of gn tile columns (tile_of) so that a group's W panels (BN x K
-    // bf16 each) stay in the XCD's 4 MB L2 next to the A row panels in flight.  Measured at M = 50432, interleaved
-    // rounds (tools/kbench.py --variants (gn+1)*1000+26): qkv (9 columns, panel 393 KB) 0.192 ms row-major, 0.174 /
-    // 0.171 / 0.175 / 0.176 for gn = 2 / 3 / 4 / 5; fc1 (12 columns) 0.276 row-major, 0.266 / 0.265 / 0.266 for gn = 2 /
-    // 4 / 5, 0.275 for 6: 1.2 - 1.6 MB of W per group (the whole forward, tools/ab_forward.py, same device: 10.54 ms row-major, 10.37 / 10.40 / 10.40 for gn = 3 / 4 / 5).  (Round 1 grouped only when W as a whole exceeded the L2; with
-    // the whole-line operand loads the L2 misses weigh more and qkv gains 10 % too.)  K = 3072 panels (1.6 MB) give
-    // gn = 1: row-major, which is all a 3-column fc2 can use anyway.
+    // bf16 each) stay in the XCD's 4 MB L2 next to the A row panels in flight.  Measured:
+    //   per launch, M = 50432, interleaved rounds (tools/kbench.py --variants (gn+1)*1000+26): qkv (9 columns, panel
+    //   393 KB) 0.192 ms row-major, 0.174 / 0.171 / 0.175 / 0.176 for gn = 2 / 3 / 4 / 5; fc1 (12 columns) 0.276
+    //   row-major, 0.266 / 0.265 / 0.266 for gn = 2 / 4 / 5, 0.275 for 6;
+    //   whole forward, same device (tools/ab_forward.py): ViT-B (K = 768) 10.54 ms row-major, 10.37 / 10.40 / 10.40 for
+    //   gn = 3 / 4 / 5; ViT-L/14 (K = 1024) 26.91 row-major, 26.47 / 26.64 for gn = 2 / 3; ViT-g/14 (K = 1536, 32 tile
+    //   columns in w12) 22.79 row-major, 20.09 / 20.07 for gn = 2 / 3 (-12 %).
+    // Rule: about 1.7 MB of W per group, i.e. gn = 4 / 3 / 2 for K = 768 / 1024 / 1536.  (Round 1 grouped only when W
+    // as a whole exceeded the L2; with the whole-line operand loads the L2 misses weigh more and qkv gains too.)
+    // K >= 3072 panels (>= 1.6 MB) give gn = 1: row-major, which is all a 3-column fc2 can use anyway.
     VDR_KNOB int gn_env = tuning_env("VDR_GEMM_GN", -1);
     const size_t panel = (size_t)BN * a.K * 2;
-    int gn = (int)((1300u << 10) / panel);
+    int gn = (int)((1700u << 10) / panel);
     if (gn < 2 || gn >= k.tiles_n) gn = 0;  // a single column at a time re-reads A once per column: never better than row-major
     k.gn = g_gemm_gn >= 0 ? g_gemm_gn : gn_env >= 0 ? gn_env : gn;
   }
