@@ -11,6 +11,8 @@
 // i.e. exactly the two ds_read_b128 the bf16 kernel issues for its two k-steps, concatenated.  The scales of a
 // unit (2 blocks x 64 rows of A and of W per wave) arrive by ONE extra 4-byte global_load_lds per wave into a
 // wave-private 256-byte region of the slot; a lane fetches the pair for its two row tiles with one ds_read_u16.
+#include <cstdlib>
+
 #include "gemm_epi.h"
 
 namespace vdr {
@@ -47,7 +49,8 @@ VDR_DEV void gemm_mx_body(const GemmK& p, char* smem) {
   static_assert((NST - 1) * G <= 63, "vmcnt range");
 
   const int wg = xcd_remap(blockIdx.x, p.nwg);
-  const int tm = wg / p.tiles_n, tn = wg - tm * p.tiles_n;
+  int tm, tn;
+  tile_of(p, wg, tm, tn);  // column groups of gn tile columns (launch_mx_cfg), as in the bf16 kernels
   const int64_t m0 = (int64_t)tm * BM;
   const int n0 = tn * BN;
 
@@ -236,6 +239,16 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.off = a.omap.off;
   const int64_t tiles_m = (a.M + BM - 1) / BM;
   k.tiles_n = (a.N + BN - 1) / BN;
+  k.tiles_m = (int)tiles_m;
+  {
+    // tile order: about 1.7 MB of W payload per column group (gemm_kernels.h, launch_cfg; an e4m3 panel is BN x K bytes)
+    int gn = (int)((1700u << 10) / ((size_t)BN * a.K));
+    if (gn < 2 || gn >= k.tiles_n) gn = 0;
+    k.gn = gn;
+#ifdef VDR_TUNING
+    if (const char* e = getenv("VDR_MX_GN")) k.gn = atoi(e);
+#endif
+  }
   const int64_t nwg = tiles_m * k.tiles_n;
   if (nwg <= 0 || nwg > 0x7fffffff) return hipErrorInvalidValue;
   k.nwg = (int)nwg;
