@@ -451,14 +451,15 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
       rs = t.y;
     }
     const int row = it * 16 + r15;
+    const float nrm = -rs * mu;  // rs (acc - mu c) + b  =  rs acc + (b - rs mu c): two fused multiply-adds per value
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       bf16x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = acc.t[jt][it][e];
-        if (p.ln_fold) v = rs * (v - mu * csum[jt][e]);
-        v += bias[jt][e];
+        if (p.ln_fold) v = fmaf(rs, v, fmaf(nrm, csum[jt][e], bias[jt][e]));
+        else v += bias[jt][e];
         if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
         o[e] = (bf16_t)v;
       }
