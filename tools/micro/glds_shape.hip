@@ -1,7 +1,7 @@
 // What does the per-CU L2 -> LDS path deliver for the access SHAPES a GEMM operand ring can use?
 // Every workgroup streams K-steps of a [rows][K] bf16 matrix (row stride K*2 bytes) into an LDS ring with
 // global_load_lds_dwordx4, a counted vmcnt keeping `ahead` steps in flight, exactly like gemm_ring3_body.
-//   shape 0: 16 rows x  64 B per wave-instruction (the 32-deep units of ring2/ring3: half cache lines)
+//   shape 0: 16 rows x  64 B per wave-instruction (the 32-deep units of a row-major operand, ring3: half cache lines)
 //   shape 1:  8 rows x 128 B per wave-instruction (64-deep units: whole 128-B lines)
 //   shape 2:  4 rows x 256 B per wave-instruction (128-deep units)
 //   shape 3: 1 KB contiguous (upper bound)

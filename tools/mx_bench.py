@@ -42,7 +42,7 @@ for name, M, N, K in shapes:
             res.append(f"mx v{v} act->bf16 {t:.3f}")
             t = timeit(lambda: ops.linear_mx(xq, wq, bias=b, epilogue=epi, variant=v, mx_out=True))
             res.append(f"mx v{v} act->mx {t:.3f}")
-        t = timeit(lambda: ops.linear(x, w, bias=b, epilogue=epi, variant=19))
+        t = timeit(lambda: ops.linear(x, w, bias=b, epilogue=epi, variant=26))
         res.append(f"bf16 v19 act {t:.3f}")
     t = timeit(lambda: ops.mx_quantize(x))
     res.append(f"quant {t:.3f} ms")

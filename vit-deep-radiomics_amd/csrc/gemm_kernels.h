@@ -45,7 +45,7 @@ VDR_DEV const bf16_t* w_unit_src(const GemmK& p, int gr, int c) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Ring variant 3: the ring2 pipeline on the 16x16x32 MFMA shape.  Same LDS image, same bytes read per unit
+// Ring variant 3: round 1's ring pipeline (32-deep units of both operands, 32x32x16 MFMA) on the 16x16x32 MFMA shape.  Same LDS image, same bytes read per unit
 // (8 ds_read_b128 per wave), same MFMA cycles (16 instructions of 4 passes instead of 8 of 8) -- but the chip
 // holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7): measured here, same box,
 // alternating processes, -5 ... -10 % on every GEMM of the forward.

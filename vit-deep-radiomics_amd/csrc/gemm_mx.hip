@@ -3,7 +3,7 @@
 // operand bytes).  BASELINE config 5 (DINOv2 ViT-g/14, fp8 weights): qkv / w12 / w3 (fc1 / fc2) run here,
 // with the activations re-quantised per 32-element block by their producers (LayerNorm, fc1 epilogue).
 //
-// Same skeleton as gemm_ring2_kernel (gemm.hip): a ring of NST LDS slots filled by 16-byte global_load_lds,
+// Same skeleton as the bf16 ring kernels (gemm_kernels.h): a ring of NST LDS slots filled by 16-byte global_load_lds,
 // counted vmcnt, raw s_barrier, LDS-staged fused epilogue.  A 64-byte LDS row is now 64 K elements = ONE
 // scaled MFMA per 32x32 tile pair: measured operand layout (tools/micro/mxfp8_test.hip) is
 //   lane (r, h): registers 0-3 = K bytes [16h, 16h+16) of scale block 0, registers 4-7 = the same of block 1,
@@ -34,7 +34,7 @@ VDR_DEV i32x8 cat_frag(const u32x4& lo, const u32x4& hi) {
   return r;
 }
 
-// (the body takes the LDS base as a plain pointer argument, like gemm_ring2_body: with the __shared__ array
+// (the body takes the LDS base as a plain pointer argument, like the bf16 ring bodies: with the __shared__ array
 // referenced directly hipcc puts an s_waitcnt vmcnt(0) -- "LDS-DMA may alias" -- in front of every ds_read)
 template <int WAVES_M, int WAVES_N, int NST, int EPI>
 VDR_DEV void gemm_mx_body(const GemmK& p, char* smem) {
