@@ -108,10 +108,10 @@ int main(int argc, char** argv) {
     run<1, 3>(src, K2, rows, 8, 2, priv, " 8r x 128B (BK64)");
     run<2, 3>(src, K2, rows, 8, 2, priv, " 4r x 256B (BK128)");
     run<3, 3>(src, K2, rows, 8, 2, priv, "contiguous 1 KB");
-    // one 8-wave workgroup per CU, deeper per-wave issue (256 x 256 x 64 tile: 64 KB per step -> G = 8)
-    run<0, 8>(src, K2, rows, 8, 1, priv, "16r x 64B  (BK32)");
-    run<1, 8>(src, K2, rows, 8, 1, priv, " 8r x 128B (BK64)");
-    run<3, 8>(src, K2, rows, 8, 1, priv, "contiguous 1 KB");
+    // one 8-wave workgroup per CU, deeper per-wave issue (48 KB per step -> G = 6; 3 steps = 144 KB of LDS)
+    run<0, 6>(src, K2, rows, 8, 1, priv, "16r x 64B  (BK32)");
+    run<1, 6>(src, K2, rows, 8, 1, priv, " 8r x 128B (BK64)");
+    run<3, 6>(src, K2, rows, 8, 1, priv, "contiguous 1 KB");
     // one 4-wave workgroup per CU
     run<0, 8>(src, K2, rows, 4, 1, priv, "16r x 64B  (BK32)");
     run<1, 8>(src, K2, rows, 4, 1, priv, " 8r x 128B (BK64)");
