@@ -72,10 +72,14 @@ class Engine:
         if not torch.cuda.is_available():
             raise L.VdrError(-2, "no HIP device visible: libvdr has no CPU path")
         self.cfg = cfg
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise L.VdrError(-1, f"libvdr runs on a HIP device, got {dev}")
+        # always an indexed device: torch.device("cuda") means the current one
+        self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
         h = C.c_void_p()
         cc = cfg.to_c()
-        L.check(self.lib.vdr_create(C.byref(cc), self.device.index or 0, C.byref(h)))
+        L.check(self.lib.vdr_create(C.byref(cc), self.device.index, C.byref(h)))
         self.h = h
         self._ws = None
         self._loaded = False
