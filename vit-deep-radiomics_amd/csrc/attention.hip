@@ -168,13 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     // mask keys >= seq (only tiles that straddle or lie beyond the end)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (kc0 + t * 32 + 32 > len) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = kc0 + t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (key >= len) s[t][e] = -INFINITY;
-        }
-      }
+      if (kc0 + t * 32 + 32 > len) mask_keys(s[t], kc0 + t * 32, hh, len);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -366,13 +360,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     if (next_item >= 0) load_q(next_item, qt, qf);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t * 32 + 32 > p.seq) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int key = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          if (key >= p.seq) s[t][e] = -INFINITY;
-        }
-      }
+      if (t * 32 + 32 > p.seq) mask_keys(s[t], t * 32, hh, p.seq);
     }
     float mx = -INFINITY;
 #pragma unroll

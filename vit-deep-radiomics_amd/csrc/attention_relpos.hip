@@ -191,11 +191,9 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
         const float b0 = relh[kh0] + relw[kw0];
         const float b1 = relh[kh1] + relw[kw1];
         const float bias = hh ? b1 : b0;
-        float l = fmaf(s[t][e], 0.125f, bias);
-        const int key = kc0 + k0 + 4 * hh;
-        if (kc0 + t * 32 + 32 > p.seq) l = key >= p.seq ? -INFINITY : l;
-        s[t][e] = l;
+        s[t][e] = fmaf(s[t][e], 0.125f, bias);
       }
+      if (kc0 + t * 32 + 32 > p.seq) mask_keys(s[t], kc0 + t * 32, hh, p.seq);
     }
     float mx = -INFINITY;
 #pragma unroll

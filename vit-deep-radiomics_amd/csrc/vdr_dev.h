@@ -53,6 +53,20 @@ VDR_DEV float gelu_erf(float x) {
 
 VDR_DEV float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-x * 1.44269504088896341f)); }
 
+// Key mask of one 32-key tile of the attention kernels: accumulator element e of lane (.., hh) is key
+// k0 + (e & 3) + 8 (e >> 2) + 4 hh; keys >= len get -inf.  Written as (constant >= per-lane threshold) with the threshold
+// made opaque on every call: comparing `key >= len` directly let hipcc hoist all 16 x NT lane masks out of the item loop
+// (they depend on the lane and the sequence length only), keep them in SGPR pairs, run out of SGPRs and spill them to
+// VGPR lanes -- 229 v_writelane + 229 v_readlane + 164 s_nop per pass of the persistent kernel's loop.  Call it inside a
+// wave-uniform `if (k0 + 32 > len)`: the asm statement also keeps that a real branch.
+VDR_DEV void mask_keys(f32x16& s, int k0, int hh, int len) {
+  int thr = len - k0 - 4 * hh;
+  asm volatile("" : "+v"(thr));
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((e & 3) + 8 * (e >> 2) >= thr) s[e] = -INFINITY;
+}
+
 // One output row of the attention kernels (64 head dims, bf16): in the S^T / O^T accumulator layout lane (row, hh) holds
 // dims nd*32 + 8g + 4hh + e (e = 0..3) and its partner lane (xor 32) the other 4 of every 8.  One v_permlane32_swap per
 // dword gives the lower lane dims 8g .. 8g+7 and the upper lane 8(g+1) .. 8(g+1)+7 of each group pair: 4 stores of
