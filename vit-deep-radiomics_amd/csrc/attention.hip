@@ -33,7 +33,19 @@ struct AttnK {
   int len_add;       //           (variable-length token sequences padded to seq)
   uint8_t* o_scale;  // non-null: `out` is an MX-fp8 payload [tokens][heads*64] and this its e8m0 scale array
   int64_t os_rows;   //           (mx.hip layout: [heads*2 blocks][os_rows], rows paired inside 64-row groups)
+#ifdef VDR_ATTN_STAMPS
+  unsigned long long* stamps;  // tools/micro/attn_stamps.hip: [workgroup][wave][item][16] cycle stamps of the phases
+#endif
 };
+
+#ifdef VDR_ATTN_STAMPS
+#ifndef VDR_ABL
+#define VDR_ABL 0  // tools/micro/attn_stamps.hip ablations: 1 no exp, 2 no pass 1, 4 no P.V MFMAs, 8 no row sum, 16 stage once, 32 no stores
+#endif
+#define VDR_STAMP(i) st[i] = __builtin_readcyclecounter()
+#else
+#define VDR_STAMP(i)
+#endif
 
 // One output row (token `grow`, head `hd`): this lane holds dims nd*32 + 8g + 4hh + e of it, its partner lane
 // (xor 32) the other half of each 32-dim block.  bf16 store, or -- fp8 path, operand of the MX out-projection --
@@ -94,16 +106,24 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
 #pragma unroll
   for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
 
-  const int b = blockIdx.x / p.heads;
-  const int hd = blockIdx.x - b * p.heads;
+  // 1-D grid of (image, head) x query blocks, query block fastest, walked in XCD-contiguous order: the query blocks of
+  // one (image, head) run next to each other on ONE XCD and find its K / V in that L2.  (As a 2-D grid with the query
+  // block on y they were a whole grid row apart: every block re-read K / V from HBM -- ViT-L/14@336, 5 query blocks
+  // per head: 0.83 GB per launch at 5.2 TB/s.)
+  const int nqt = (p.seq + 31) >> 5;
+  const int nyb = (nqt + p.qt_per_block - 1) / p.qt_per_block;
+  const int vid = nyb > 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bh = vid / nyb;
+  const int yb = vid - bh * nyb;
+  const int b = bh / p.heads;
+  const int hd = bh - b * p.heads;
   const int HD = p.heads * 64;
   const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
   const int len = p.lens ? min(p.seq, p.lens[b] + p.len_add) : p.seq;  // valid keys of this sequence
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
 
-  const int nqt = (p.seq + 31) >> 5;
-  const int qt_begin = blockIdx.y * p.qt_per_block;
+  const int qt_begin = yb * p.qt_per_block;
   const int qt_end = min(nqt, qt_begin + p.qt_per_block);
   const float sc = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
 
@@ -256,12 +276,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
 //   latency that the one-shot kernel exposes at the head of every workgroup (52 % of its wave-cycles
 //   were waits) sits under the MFMAs.
 // -------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_items) {
+// LOADER: an eighth wave (512 threads) issues ALL of the next item's DMA pieces and nothing else; the seven computing
+// waves issue none.  An LDS-DMA instruction costs its wave 100-400 cycles of issue in a busy phase (stamped: 8 pieces
+// per wave and item took 3 k of a 20 k-cycle item in the two-pass kernel below), and the loader sits on the SIMD that
+// holds only one computing wave (7 tiles on 4 SIMDs: 2, 2, 2, 1).
+template <int NT, bool LOADER>
+__global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(AttnK p, int n_items) {
   constexpr int KEYS = NT * 32;
   constexpr int BUF = 2 * KEYS * 128;                 // K image + V image, both [key][64 d] rows of 128 B
   constexpr int NCW = 7;                              // waves == query tiles served per item
-  constexpr int PPW = (NT * 8 + NCW - 1) / NCW;       // 8-row DMA pieces (K: NT*4, then V: NT*4) per wave
+  constexpr int PPW = (NT * 8 + NCW - 1) / NCW;       // 8-row DMA pieces (K: NT*4, then V: NT*4) per wave (no loader wave)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -284,6 +308,23 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     const int b = item / p.heads;
     const int hd = item - b * p.heads;
     const bf16_t* kb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64 + HD;
+    if (LOADER) {
+      // the loader wave: all NT*8 pieces, a rolled loop with the lane part of the address rebuilt per piece (kept
+      // unrolled, hipcc hoists 56 64-bit addresses out of the item loop and spills)
+      if (wave != NCW) return;
+      const uint32_t ldb = (uint32_t)p.ld_qkv * 2;
+      const int r0 = lane >> 3;
+      const uint32_t ck = (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);               // K chunk, ^ 64 on odd pieces
+      const uint32_t cv = (uint32_t)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16);  // V chunk
+#pragma unroll 2
+      for (int i = 0; i < NT * 4; ++i) {
+        const int r = i * 8 + r0;
+        const uint32_t row = (uint32_t)(r < p.seq ? r : p.seq - 1) * ldb;
+        glds16_raw(kb, row + (ck ^ (uint32_t)((i & 1) << 6)), buf + i * 1024);
+        glds16_raw(kb + HD, row + cv, buf + (NT * 4 + i) * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave + i * NCW;
@@ -292,7 +333,7 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
         const int r = (piece - isv * NT * 4) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (isv ? (((r >> 1) & 1) << 2) : ((r >> 1) & 7));
         const int key = r < p.seq ? r : p.seq - 1;
-        glds16(kb + isv * HD + (int64_t)key * p.ld_qkv + c * 8, buf + piece * 1024);
+        glds16_raw(kb + isv * HD + (int64_t)key * p.ld_qkv + c * 8, buf + piece * 1024);
       }
     }
   };
@@ -424,6 +465,11 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next item's K / V pieces and Q (issued long ago); see stage_write
+    // Retire the next item's Q fragments HERE, before the stores: hipcc meets their first "use" with a vmcnt wait of its
+    // own, and placed after the stores that wait (vmcnt(0): it does not count the predicated stores) would sit out the
+    // stores' acknowledgement every item.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
     attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
   };
 
@@ -453,19 +499,277 @@ __global__ __launch_bounds__(448, 2) void attn_persist_kernel(AttnK p, int n_ite
     if (more) stage_issue(next, smem + (cur ^ 1) * BUF);
     if (computes && do_compute) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
     if (more) stage_write(computes && do_compute);
-    // The next item's Q fragments were fetched by ordinary loads during compute_tile.  Retire them
-    // HERE (they have long landed): otherwise hipcc, which cannot count past the LDS-DMA issued at the
-    // top of the next item, would wait vmcnt(0) at their first use and expose the whole staging latency.
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
     cur ^= 1;
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Two-pass persistent variant (129 <= seq <= 208, head dim 64): the S^T tile is never held whole.
+//   The one-pass kernel above keeps all 7 score tiles of a 32-query tile in registers (112 of its 232 VGPRs), which
+//   caps a SIMD at two waves that walk the same phases in step (QK^T, max, exp / P.V): MFMA pipe busy 19 %, the wave's
+//   dependent chain is the launch time.  Here pass 1 computes the score tiles only for the row maximum and drops
+//   them; pass 2 recomputes each tile (4 MFMAs), exponentiates against the final maximum and multiplies by V at once.
+//   +50 % MFMA work (84 instead of 56 per tile-wave: the matrix pipe has the room), the same exponentials, sums and
+//   P.V products in the same order -- results are bitwise those of the one-pass kernels -- at <= 128 VGPRs: four waves
+//   per SIMD, two 7-wave workgroups per CU that drift apart and fill each other's waits.
+//   LDS per workgroup: three rotating images of 208 rows x 128 B (26 KB each; + 2 KB so that the 7th K tile's reads of
+//   rows 208..223 -- keys past the sequence, overwritten with -inf before use -- stay inside the allocation) = 80 KB.
+//   Item n: K_n sits in image kb (loaded during item n-1).  After the top barrier the other two images are free: V_n
+//   goes into kb+1, K_{n+1} into kb+2, both by LDS-DMA, under pass 1 (which reads K only); second barrier; pass 2.
+// -------------------------------------------------------------------------------------------------
+template <int NT>  // query tiles == key tiles == waves: 5 (seq 129..160), 6 (161..192), 7 (193..208)
+__global__ __launch_bounds__(NT * 64, 4) void attn_persist2_kernel(AttnK p, int n_items) {
+  constexpr int ROWS = 208;
+  constexpr int BUFB = ROWS * 128;
+  constexpr int NP = ROWS / 8;                    // 8-row DMA pieces per image
+  constexpr int PPW = (NP + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5;
+  const int l31 = lane & 31;
+  const int swz = (lane >> 1) & 7;
+  const int HD = p.heads * 64;
+  const float sc = 0.125f * 1.44269504088896341f;
+  const uint32_t ldb = (uint32_t)p.ld_qkv * 2;  // row pitch in bytes
+
+  // lane part of the source address of this wave's DMA pieces (rows past the sequence repeat the last key: finite
+  // values whose P is 0), K swizzle (key >> 1) & 7, V swizzle ((key >> 1) & 1) << 2 -- see attn_persist_kernel
+  uint32_t koff[PPW], voffs[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int r = (wave + i * NT) * 8 + (lane >> 3);
+    const int key = r < p.seq ? r : p.seq - 1;
+    koff[i] = (uint32_t)key * ldb + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    voffs[i] = (uint32_t)key * ldb + (uint32_t)(((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16);
+  }
+  auto item_base = [&](int item) {  // q of token 0 of (image, head)
+    const int b = item / p.heads;
+    const int hd = item - b * p.heads;
+    return reinterpret_cast<const char*>(p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64);
+  };
+  auto stage_k = [&](const char* base, char* buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      if (i < PPW - 1 || wave + i * NT < NP) glds16_raw(base + 2 * HD, koff[i], buf + (wave + i * NT) * 1024);
+  };
+  auto stage_v = [&](const char* base, char* buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      if (i < PPW - 1 || wave + i * NT < NP) glds16_raw(base + 4 * HD, voffs[i], buf + (wave + i * NT) * 1024);
+  };
+  int qrow = wave * 32 + l31;
+  qrow = qrow < p.seq ? qrow : p.seq - 1;
+  const uint32_t qoff = (uint32_t)qrow * ldb + hh * 16;
+  auto load_q = [&](const char* base, bf16x8 (&q)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(base + qoff + ks * 32);
+  };
+
+  const int kx = (hh ^ swz) * 16;  // 16-B chunk (2 ks + hh) ^ swz = (hh ^ swz) ^ 2 ks
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
+  const int vkey = 4 * hh + tq;
+  const int vx = vkey * 128 + 8 * (tp & 1) + ((2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;  // nd: ^ 64
+
+  bf16x8 qf[4], qn[4];
+  auto qk_tile = [&](const char* sK, int kx, int t, f32x16& s) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * 32 * 128 + (kx ^ (ks * 32)));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+    }
+    if (t == NT - 1) mask_keys(s, t * 32, hh, p.seq);  // only the last tile can hold keys past the sequence
+  };
+
+  int item = blockIdx.x;
+  if (item >= n_items) return;
+  int kb = 0;
+  {
+    const char* base = item_base(item);
+    stage_k(base, smem);
+    load_q(base, qf);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+  const int stride = __builtin_amdgcn_readfirstlane(gridDim.x);
+  const bool last_slice = (NT - 1) * 32 + 16 < p.seq;  // second 16-key slice of the last tile holds a valid key
+#ifdef VDR_ATTN_STAMPS
+  int it_no = 0;
+#endif
+  for (; item < n_items; item += stride) {
+#ifdef VDR_ATTN_STAMPS
+    unsigned long long st[16];
+#endif
+    VDR_STAMP(0);
+#ifdef VDR_ATTN_STAMPS
+    st[9] = wall_clock64();  // constant 100 MHz: calibrates the shader clock the other stamps count
+#endif
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // image kb holds K of this item (every wave waited for its pieces); the other two are free
+    asm volatile("" ::: "memory");
+    VDR_STAMP(1);
+    const int vb = kb == 2 ? 0 : kb + 1;
+    const int nb = kb == 0 ? 2 : kb - 1;
+    const int next = item + stride;
+    const bool more = next < n_items;
+    const char* base = item_base(item);
+    const char* nbase = item_base(more ? next : item);
+#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 16)
+    if (it_no == 0)
+#endif
+    {
+      stage_v(base, smem + vb * BUFB);
+      if (more) stage_k(nbase, smem + nb * BUFB);
+    }
+    const char* sK = smem + kb * BUFB + l31 * 128;
+    VDR_STAMP(2);
+
+    // ---- pass 1: row maximum ------------------------------------------------------------------------------------
+    float mx = -INFINITY;
+#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 2)
+    mx = 8.0f;
+#else
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 s;
+      qk_tile(sK, kx, t, s);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+      asm volatile("" : "+v"(mx));        // this tile's scores are dead here: one tile at a time (VGPR budget)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#endif
+    // V of this item (and K of the next, and the previous item's output stores) had pass 1 to land
+    asm volatile("" : "+v"(mx));
+    VDR_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VDR_STAMP(4);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    VDR_STAMP(5);
+
+    // ---- pass 2: recompute a tile, exponentiate, multiply by V --------------------------------------------------
+    if (more) load_q(nbase, qn);  // lands under pass 2
+    const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + vb * BUFB);
+    const float mb = mx * sc;
+    float lsum = 0.0f;
+    f32x16 o[2];
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
+    int kx2 = kx;
+    asm volatile("" : "+v"(kx2));  // opaque: otherwise hipcc keeps pass 1's score tiles (in scratch) instead of recomputing
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x16 s;
+      qk_tile(sK, kx2, t, s);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        // a slice entirely past the sequence carries P = 0: skipped (adds of +0, results unchanged)
+        if (t < NT - 1 || s2 == 0 || last_slice) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 1)
+            const float pv = fmaf(s[8 * s2 + j], sc, -mb);
+#else
+            const float pv = fast_exp2(fmaf(s[8 * s2 + j], sc, -mb));
+#endif
+#if !(defined(VDR_ATTN_STAMPS) && (VDR_ABL & 8))
+            lsum += pv;
+#endif
+            pf[j] = (bf16_t)pv;
+          }
+#pragma unroll
+          for (int nd = 0; nd < 2; ++nd) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + (t * 32 + s2 * 16) * 128 + (vx ^ (nd * 64))));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + (t * 32 + s2 * 16 + 8) * 128 + (vx ^ (nd * 64))));
+            bf16x8 vf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              vf[j] = lo[j];
+              vf[4 + j] = hi[j];
+            }
+#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 4)
+            asm volatile("" :: "v"(vf), "v"(pf));
+#else
+            o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
+#endif
+          }
+          asm volatile("" : "+v"(lsum));      // the row sum is up to date here: hipcc otherwise parks all exponentials (in scratch) and adds them at the end
+          __builtin_amdgcn_sched_barrier(0);  // keep later slices' work from being hoisted (VGPR budget)
+        }
+      }
+    }
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = wave * 32 + l31;
+    const int b = item / p.heads;
+    const int hd = item - b * p.heads;
+#ifdef VDR_ATTN_STAMPS
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+#endif
+    VDR_STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next item's Q
+    VDR_STAMP(7);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qn[ks]));  // retired by the vmcnt(0) above, BEFORE the stores (see attn_persist_kernel)
+#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 32)
+    attn_store_row(p, o, inv, q < p.seq && item > n_items, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
+#else
+    attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    VDR_STAMP(8);
+#ifdef VDR_ATTN_STAMPS
+    st[10] = wall_clock64();
+    if (lane == 0 && it_no < 8) {
+      unsigned long long* d = p.stamps + (((size_t)blockIdx.x * NT + wave) * 8 + it_no) * 16;
+      for (int i = 0; i < 11; ++i) d[i] = st[i];
+    }
+    ++it_no;
+#endif
+    kb = nb;
+  }
+}
+
 template <int NT>
+static hipError_t launch_persist2(const AttnK& k, int batch, hipStream_t s) {
+  constexpr size_t lds = 3 * 208 * 128 + 2048;  // 80 KB: two workgroups per CU
+  auto fn = attn_persist2_kernel<NT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  const int n_items = batch * k.heads;
+  const int grid = n_items < 2 * n_cu ? n_items : 2 * n_cu;
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(NT * 64), lds, s, k, n_items);
+  return hipGetLastError();
+}
+
+template <int NT, bool LOADER>
 static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(2 * NT * 32 * 128);
-  auto fn = attn_persist_kernel<NT>;
+  auto fn = attn_persist_kernel<NT, LOADER>;
   static bool attr_set = false;  // per instantiation: raised once, not per launch
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -481,7 +785,7 @@ static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
   }
   const int n_items = batch * k.heads;
   const int grid = n_items < n_cu ? n_items : n_cu;
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(448), lds, s, k, n_items);
+  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(LOADER ? 512 : 448), lds, s, k, n_items);
   return hipGetLastError();
 }
 
@@ -496,7 +800,7 @@ static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
     attr_set = true;
   }
   const int nqt = (k.seq + 31) / 32;
-  const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));
+  const dim3 grid((unsigned)(batch * k.heads * ((nqt + k.qt_per_block - 1) / k.qt_per_block)));
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
   return hipGetLastError();
 }
@@ -510,7 +814,7 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   variant %= 10;
 #else
   k.abl = 0;
-  if (variant < 0 || variant > 3) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
+  if (variant < 0 || variant > 4) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
 #endif
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
@@ -531,12 +835,16 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   }
   k.qt_per_block = nqt;
   k.n_chunks = 1;
-  if ((variant == 2 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
+  if ((variant == 2 || variant == 3 || variant == 4 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
     // persistent warp-specialised kernel (needs a few items per workgroup to pay off)
-    if (seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7>(k, batch, s);  // nqt <= 7 compute waves
+    if (variant == 3 && seq > 128 && seq <= 208)
+      return nqt == 5 ? launch_persist2<5>(k, batch, s) : nqt == 6 ? launch_persist2<6>(k, batch, s) : launch_persist2<7>(k, batch, s);
+    if (variant == 4 && seq > 128 && seq <= 224) return launch_persist<7, true>(k, batch, s);
+    if (variant == 0 && seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7, true>(k, batch, s);  // nqt <= 7 compute waves
+    if (seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7, false>(k, batch, s);
     if (variant == 2) {
-      if (seq <= 128) return launch_persist<4>(k, batch, s);
-      if (seq <= 224) return launch_persist<7>(k, batch, s);
+      if (seq <= 128) return launch_persist<4, false>(k, batch, s);
+      if (seq <= 224) return launch_persist<7, false>(k, batch, s);
     }
   }
   if (seq <= 64) return launch_nt<2>(k, batch, s);

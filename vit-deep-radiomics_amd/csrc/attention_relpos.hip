@@ -58,9 +58,15 @@ struct AttnRK {
   int n_chunks;
 };
 
+// Workgroup: 4 waves.  (MULTI with 8 waves = 8 query tiles per workgroup, half the LDS-DMA pieces per wave and half the
+// K / V bytes per query, measured SLOWER: 8.05 -> 8.71 ms per MedSAM step at B = 16 -- one 8-wave workgroup per CU loses
+// the second workgroup that runs while the first sits at its chunk barrier.)
 template <int NT, int S, bool MULTI>
 __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   constexpr int KEYS = NT * 32;
+  constexpr int NW = 4;                   // waves
+  constexpr int PPW = NT * 4 / NW;        // K (and V) pieces of 8 rows per wave and image
+  static_assert(NT * 4 % NW == 0 || !MULTI, "pieces must divide among the waves");
   static_assert(!MULTI || (S == 64 && NT == 4), "the chunked form assumes 128-key chunks = two rows of a 64-wide grid");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUF = 2 * KEYS * 128;  // K image + V image; the chunked (MULTI) form ping-pongs between two of them
@@ -80,26 +86,37 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
 #pragma unroll
   for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
 
-  const int b = blockIdx.x / p.heads;
-  const int hd = blockIdx.x - b * p.heads;
+  // 1-D grid of (window or grid, head) x query blocks in XCD-contiguous order (see attention.hip: attn_kernel).  The
+  // 32 query blocks of one global-attention head now share their XCD's L2 for its 1 MB of K / V instead of each
+  // streaming it from HBM: 6.4 GB per launch at B = 16 before.
+  const int nqt = (p.seq + 31) >> 5;
+  const int nyb = (nqt + p.qt_per_block - 1) / p.qt_per_block;
+  const int vid = nyb > 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bh = vid / nyb;
+  const int yb = vid - bh * nyb;
+  const int b = bh / p.heads;
+  const int hd = bh - b * p.heads;
   const int HD = p.heads * 64;
   const bf16_t* qb = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64;
   const bf16_t* kb = qb + HD;
   const bf16_t* vb = qb + 2 * HD;
   bf16_t* ob = p.out + (int64_t)b * p.seq * p.ld_out + hd * 64;
 
-  const int nqt = (p.seq + 31) >> 5;
-  const int qt_begin = blockIdx.y * p.qt_per_block;
+  const int qt_begin = yb * p.qt_per_block;
   const int qt_end = min(nqt, qt_begin + p.qt_per_block);
   constexpr float LOG2E = 1.44269504088896341f;
 
   f32x16 o[2];
   float m_run = -INFINITY, l_run = 0.0f;
   bf16x8 qf[4];
-  constexpr int NRW = S;                 // rel_w values kept in registers
+  // rel_w values kept in registers: the whole row, or (MULTI) the 32 columns this lane's accumulator elements ever meet
+  // -- element e of an even / odd 32-key tile is column (tile & 1) * 32 + (e & 3) + 8 (e >> 2) + 4 hh, so a lane needs
+  // 2 x 16 of the 64 and the upper lane half simply loads its own, shifted, set: no per-element select between halves
+  constexpr int NRW = MULTI ? 32 : S;
   constexpr int NRH = MULTI ? 2 : S;     // rel_h values: the whole column, or the chunk's two grid rows
   constexpr int NPAD = 2 * ((2 * S - 1 + 31) / 32 * 32);  // relpos_npad(S)
-  float relw[NRW], relh[NRH];
+  float relw[MULTI ? 1 : NRW], relh[NRH];
+  f32x16 rw8[2];  // MULTI: 8 x rel_w of the lane's 16 columns in an even / odd 32-key tile -- the QK^T accumulators START from these
   const float* relrow = nullptr;
 
   auto load_q = [&](int qt) {
@@ -113,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     relrow = trow + qh + (S - 1);  // rel_h[kh] = relrow[-kh]
     const float* wrow = trow + NPAD / 2 + qw + (S - 1);
 #pragma unroll
-    for (int j = 0; j < NRW; ++j) relw[j] = wrow[-j];
+    for (int j = 0; j < NRW; ++j) {
+      if constexpr (MULTI) rw8[j >> 4][j & 15] = 8.0f * wrow[-((j >> 4) * 32 + (j & 3) + 8 * ((j & 15) >> 2) + 4 * hh)];  // (x 8: see process)
+      else relw[j] = wrow[-j];
+    }
     if (!MULTI) {
 #pragma unroll
       for (int j = 0; j < NRH; ++j) relh[j] = relrow[-j];
@@ -126,9 +146,28 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     l_run = 0.0f;
   };
 
+  // MULTI: the lane part of a piece's source address does not depend on the chunk (seq is a whole number of chunks:
+  // no clamp); kept as 32-bit offsets beside a wave-uniform base that moves by one chunk
+  uint32_t koff[MULTI ? PPW : 1], voff[MULTI ? PPW : 1];
+  if (MULTI) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int r = (wave * PPW + q) * 8 + (lane >> 3);
+      koff[q] = (uint32_t)r * (uint32_t)(p.ld_qkv * 2) + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+      voff[q] = (uint32_t)r * (uint32_t)(p.ld_qkv * 2) + (uint32_t)(((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16);
+    }
+  }
   auto stage_issue = [&](int kc0, char* buf) {
     char* sK = buf;
     char* sVt = buf + KEYS * 128;
+    if (MULTI) {
+      const bf16_t* kc = kb + (int64_t)kc0 * p.ld_qkv;
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) glds16_raw(kc, koff[q], sK + (wave * PPW + q) * 1024);
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) glds16_raw(kc + HD, voff[q], sVt + (wave * PPW + q) * 1024);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int piece = wave * NT + q;
@@ -136,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       int key = kc0 + r;
       key = key < p.seq ? key : p.seq - 1;
-      glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
+      glds16_raw(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
     }
     // V rows the same way (row-major, chunk ^ (((key >> 1) & 1) << 2)): consumed by ds_read_b64_tr_b16 below, so no
     // register-staged transpose; rows past the sequence repeat the last key (their P is exp(-inf) = 0)
@@ -147,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
       const int c = (lane & 7) ^ (((r >> 1) & 1) << 2);
       int key = kc0 + r;
       key = key < p.seq ? key : p.seq - 1;
-      glds16(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
+      glds16_raw(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
     }
   };
   auto stage_wait = [&]() {
@@ -158,52 +197,58 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
   auto process = [&](int kc0, bool rescale, const char* buf) {
     const char* sK = buf;
     const __attribute__((address_space(3))) char* sVtr = (const __attribute__((address_space(3))) char*)buf + vbase;
-    if (MULTI) {
-      // this chunk covers grid rows kc0/64 and kc0/64 + 1
-      relh[0] = relrow[-(kc0 >> 6)];
-      relh[1] = relrow[-min((kc0 >> 6) + 1, S - 1)];
-    }
     f32x16 s[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      // MULTI: the first MFMA takes 8 rel_w[kw] as its C operand (registers that never change: no per-element add, no
+      // copy) and the rest add q.k on top; 8 rel_h[kh] is constant over a tile (grid row t >> 1 of the chunk) and enters
+      // the row maximum and the exp2 offset below.  logits = (acc + 8 rel_h) / 8, the 1/8 folded into the exp2 scale.
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf =
             *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * 128 + (((2 * ks + hh) ^ swz) * 16));
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], (MULTI && ks == 0) ? rw8[t & 1] : s[t], 0, 0, 0);
       }
     }
-    // logits = s * dh^-0.5 + rel_h[kh] + rel_w[kw]; the (chunk-local) key of element (t, e, half) is static
+    // windows: logits = s * dh^-0.5 + rel_h[kh] + rel_w[kw]; the key of element (t, e, half) is static
+    if constexpr (!MULTI) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int k0 = t * 32 + (e & 3) + 8 * (e >> 2);  // half 0; half 1 is k0 + 4
-        const int k1 = k0 + 4;
-        const int kh0 = MULTI ? (k0 >> 6) : (k0 / S < S ? k0 / S : S - 1);
-        const int kh1 = MULTI ? (k1 >> 6) : (k1 / S < S ? k1 / S : S - 1);
-        const int kw0 = MULTI ? (k0 & 63) : k0 % S;
-        const int kw1 = MULTI ? (k1 & 63) : k1 % S;
-        const float b0 = relh[kh0] + relw[kw0];
-        const float b1 = relh[kh1] + relw[kw1];
-        const float bias = hh ? b1 : b0;
-        s[t][e] = fmaf(s[t][e], 0.125f, bias);
+        for (int e = 0; e < 16; ++e) {
+          const int k0 = t * 32 + (e & 3) + 8 * (e >> 2);  // half 0; half 1 is k0 + 4
+          const int k1 = k0 + 4;
+          const int kh0 = k0 / S < S ? k0 / S : S - 1;
+          const int kh1 = k1 / S < S ? k1 / S : S - 1;
+          const float b0 = relh[kh0] + relw[k0 % S];
+          const float b1 = relh[kh1] + relw[k1 % S];
+          const float bias = hh ? b1 : b0;
+          s[t][e] = fmaf(s[t][e], 0.125f, bias);
+        }
+        if (kc0 + t * 32 + 32 > p.seq) mask_keys(s[t], kc0 + t * 32, hh, p.seq);
       }
-      if (kc0 + t * 32 + 32 > p.seq) mask_keys(s[t], kc0 + t * 32, hh, p.seq);
     }
+    constexpr float SC = MULTI ? 0.125f * LOG2E : LOG2E;  // exp2 scale of the values held in s[]
     float mx = -INFINITY;
+    if constexpr (MULTI) {
+      float mrow[2] = {-INFINITY, -INFINITY};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+        for (int e = 0; e < 16; ++e) mrow[t >> 1] = fmaxf(mrow[t >> 1], s[t][e]);
+      mx = fmaxf(mrow[0] + relh[0], mrow[1] + relh[1]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     if (rescale) {
-      const float alpha = fast_exp2((m_run - m_new) * LOG2E);
+      const float alpha = fast_exp2((m_run - m_new) * SC);
       l_run *= alpha;
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd)
@@ -211,7 +256,10 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
         for (int e = 0; e < 16; ++e) o[nd][e] *= alpha;
     }
     m_run = m_new;
-    const float mb = m_new * LOG2E;
+    const float mb = m_new * SC;
+    float crow[2];  // exp2 offset of a tile: -max (+ 8 rel_h of its grid row), scaled
+    crow[0] = MULTI ? fmaf(relh[0], SC, -mb) : -mb;
+    crow[1] = MULTI ? fmaf(relh[1], SC, -mb) : -mb;
     float lsum = 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -220,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], LOG2E, -mb));
+          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], SC, crow[MULTI ? t >> 1 : 0]));
           lsum += pv;
           pf[j] = (bf16_t)pv;
         }
@@ -261,12 +309,37 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     const int qt = qt_begin + wave;
     const bool valid = qt < qt_end;
     load_q(valid ? qt : qt_begin);
-    // double-buffered: chunk c+1 streams into the other buffer while chunk c is processed; one barrier per chunk
+    // double-buffered: chunk c+1 streams into the other buffer while chunk c is processed; one barrier per chunk.
+    // The LDS-DMA is issued as an opaque instruction (glds16_raw) so that hipcc orders nothing after it; what it
+    // still does is meet the first use of every ordinary load with a `vmcnt(n)` counted over the loads IT knows,
+    // which -- vmcnt retires in issue order -- would wait for the DMA pieces issued before them as well.  So every
+    // register filled by a load is "used" (empty asm) right after the explicit vmcnt(0) of stage_wait and nowhere
+    // else first: q / rel_w after the first one, the two rel_h values of a chunk (grid rows kc0/64, kc0/64 + 1)
+    // one chunk ahead, after the wait that ends the chunk before.  (With the builtin DMA and the rel_h loads inside process() every chunk sat out the whole
+    // latency of the prefetch it had just issued.)
+    float rh_next[2];
+    auto load_relh = [&](int kc0) {
+      rh_next[0] = relrow[-(kc0 >> 6)];  // (scaled by 8 where they are retired: arithmetic on them here would be a use)
+      rh_next[1] = relrow[-min((kc0 >> 6) + 1, S - 1)];
+    };
+    load_relh(0);
     stage_issue(0, smem);
+    stage_wait();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(rw8[j]));
     for (int c = 0; c < p.n_chunks; ++c) {
-      stage_wait();
-      if (c + 1 < p.n_chunks) stage_issue((c + 1) * KEYS, smem + ((c + 1) & 1) * BUF);
+      asm volatile("" : "+v"(rh_next[0]), "+v"(rh_next[1]));
+      relh[0] = 8.0f * rh_next[0];
+      relh[1] = 8.0f * rh_next[1];
+      const bool more = c + 1 < p.n_chunks;
+      if (more) {
+        load_relh((c + 1) * KEYS);
+        stage_issue((c + 1) * KEYS, smem + ((c + 1) & 1) * BUF);
+      }
       if (valid) process(c * KEYS, c > 0, smem + (c & 1) * BUF);
+      if (more) stage_wait();
     }
     if (valid) store(qt);
   }
@@ -283,7 +356,7 @@ static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
     attr_set = true;
   }
   const int nqt = (k.seq + 31) / 32;
-  const dim3 grid((unsigned)(batch * k.heads), (unsigned)((nqt + k.qt_per_block - 1) / k.qt_per_block));
+  const dim3 grid((unsigned)(batch * k.heads * ((nqt + k.qt_per_block - 1) / k.qt_per_block)));
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
   return hipGetLastError();
 }

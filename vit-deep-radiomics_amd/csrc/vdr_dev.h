@@ -20,6 +20,24 @@ VDR_DEV void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy as one opaque instruction: wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset, LDS
+// destination = wave-uniform byte address `lds_addr`, handed over in M0 (+ lane*16 by the hardware).  hipcc does not see a memory
+// operation here, which is the point: with the builtin it makes every later LDS read that it cannot prove disjoint
+// from the DMA's destination (all ds_read_b64_tr_b16 reads, for one) wait `vmcnt(0)` first -- i.e. for the whole
+// prefetch that was meant to stay in flight under the arithmetic.  The caller orders the data itself: a counted
+// `s_waitcnt vmcnt` + workgroup barrier before the first read of the image (cdna_hip_programming.md §7).
+VDR_DEV void glds16_raw(const void* base_uniform, uint32_t lane_off, const void* lds_wave_base) {
+  const uint32_t lds_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"  // (s_nop: one wait state between the write of M0 and its use)
+               :: "v"(lane_off), "s"(base_uniform), "{m0}"(lds_addr) : "memory");
+}
+
+// ... and with a per-lane 64-bit source address (no uniform base at hand)
+VDR_DEV void glds16_raw(const void* gsrc, const void* lds_wave_base) {
+  const uint32_t lds_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds_wave_base;
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "{m0}"(lds_addr) : "memory");
+}
+
 VDR_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
