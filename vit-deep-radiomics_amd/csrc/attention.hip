@@ -34,14 +34,11 @@ struct AttnK {
   uint8_t* o_scale;  // non-null: `out` is an MX-fp8 payload [tokens][heads*64] and this its e8m0 scale array
   int64_t os_rows;   //           (mx.hip layout: [heads*2 blocks][os_rows], rows paired inside 64-row groups)
 #ifdef VDR_ATTN_STAMPS
-  unsigned long long* stamps;  // tools/micro/attn_stamps.hip: [workgroup][wave][item][16] cycle stamps of the phases
+  unsigned long long* stamps;  // tools/micro/attn_stamps.hip: [workgroup][8 waves][16 items][16] cycle stamps of the phases
 #endif
 };
 
 #ifdef VDR_ATTN_STAMPS
-#ifndef VDR_ABL
-#define VDR_ABL 0  // tools/micro/attn_stamps.hip ablations: 1 no exp, 2 no pass 1, 4 no P.V MFMAs, 8 no row sum, 16 stage once, 32 no stores
-#endif
 #define VDR_STAMP(i) st[i] = __builtin_readcyclecounter()
 #else
 #define VDR_STAMP(i)
@@ -146,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     l_run = 0.0f;
   };
 
-  auto stage = [&](int kc0) {
+  // staging of one key chunk.  The LDS-DMA is an opaque instruction (glds16_raw): hipcc orders nothing after it, the
+  // explicit vmcnt(0) + barrier of stage_wait does.
+  auto stage_issue = [&](int kc0) {
     // K: KEYS rows of 128 B, 8 rows per wave-instruction
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       int key = kc0 + r;
       key = key < p.seq ? key : p.seq - 1;
-      glds16(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
+      glds16_raw(kb + (int64_t)key * p.ld_qkv + c * 8, sK + piece * 1024);
     }
     // V rows the same way (row-major, chunk ^ (((key >> 1) & 1) << 2)), consumed by ds_read_b64_tr_b16 in process():
     // no register-staged transpose; rows past the sequence repeat the last key (their P is exp(-inf) = 0)
@@ -166,8 +165,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
       const int c = (lane & 7) ^ (((r >> 1) & 1) << 2);
       int key = kc0 + r;
       key = key < p.seq ? key : p.seq - 1;
-      glds16(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
+      glds16_raw(vb + (int64_t)key * p.ld_qkv + c * 8, sVt + piece * 1024);
     }
+  };
+  auto stage_wait = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -246,25 +247,29 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
   };
 
   if (p.n_chunks == 1) {
-    stage(0);
+    stage_issue(0);
+    stage_wait();
     for (int qt = qt_begin + wave; qt < qt_end; qt += 4) {
       load_q(qt);
       process(0, false);
       store(qt);
     }
   } else {
+    // One image pair, restaged per chunk: at 164 VGPRs and 32 KB of LDS three workgroups share a CU and compute while
+    // this one waits.  (Ping-pong images with the next chunk's DMA in flight under process() take 170 VGPRs and 64 KB --
+    // two workgroups per CU -- and measured slower: ViT-L/14@336 attention 3.46 -> 3.74 ms per step.)
     const int qt = qt_begin + wave;
     const bool valid = qt < qt_end;  // wave-uniform
     load_q(valid ? qt : qt_begin);
     for (int c = 0; c < p.n_chunks; ++c) {
       if (c) __syncthreads();  // every wave is done reading the previous chunk
-      stage(c * KEYS);
+      stage_issue(c * KEYS);
+      stage_wait();
       if (valid) process(c * KEYS, c > 0);
     }
     if (valid) store(qt);
   }
 }
-
 
 // -------------------------------------------------------------------------------------------------
 // Persistent variant for single-chunk sequences (seq <= NT*32, at most 7 query tiles):
@@ -297,6 +302,9 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
   const int HD = p.heads * 64;
   const int nqt = (p.seq + 31) >> 5;
   const float sc = 0.125f * 1.44269504088896341f;
+#ifdef VDR_ATTN_STAMPS
+  unsigned long long st[16] = {};  // tools/micro/attn_stamps.hip: s_memtime at the phase boundaries of the current item
+#endif
 
   // ---- staging of one item: K and V rows straight into LDS by global_load_lds, no registers -------
   //   K: 16-B chunk ^ ((key >> 1) & 7)            (ds_read_b128 row reads of the 32x32x16 operand)
@@ -397,6 +405,11 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i & 1], qf[ks], s[t], 0, 0, 0);
       }
     }
+#ifdef VDR_ATTN_STAMPS
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(s[t]));
+#endif
+    VDR_STAMP(2);
     // qf is dead from here: fetch the next item's Q into it; the loads land under the softmax / P.V
     if (next_item >= 0) load_q(next_item, qt, qf);
 #pragma unroll
@@ -410,6 +423,10 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mb = mx * sc;
+#ifdef VDR_ATTN_STAMPS
+    asm volatile("" : "+v"(mx));
+#endif
+    VDR_STAMP(3);
     float lsum = 0.0f;
     f32x16 o[2];
 #pragma unroll
@@ -464,13 +481,19 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;
+#ifdef VDR_ATTN_STAMPS
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+#endif
+    VDR_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next item's K / V pieces and Q (issued long ago); see stage_write
+    VDR_STAMP(5);
     // Retire the next item's Q fragments HERE, before the stores: hipcc meets their first "use" with a vmcnt wait of its
     // own, and placed after the stores that wait (vmcnt(0): it does not count the predicated stores) would sit out the
     // stores' acknowledgement every item.
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
     attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
+    VDR_STAMP(6);
   };
 
   int item = blockIdx.x;
@@ -484,10 +507,18 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
   for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));  // retired by the vmcnt(0) just above
   int cur = 0;
   const int stride = __builtin_amdgcn_readfirstlane(gridDim.x);  // (kept in an SGPR: the memory clobbers below would re-read it)
+#ifdef VDR_ATTN_STAMPS
+  int it_no = 0;
+#endif
   for (; item < n_items; item += stride) {
+    VDR_STAMP(0);
+#ifdef VDR_ATTN_STAMPS
+    st[9] = wall_clock64();  // constant 100 MHz: calibrates the shader clock the other stamps count
+#endif
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();  // buffer `cur` holds this item; the other buffer is free
     asm volatile("" ::: "memory");
+    VDR_STAMP(1);
     const int next = item + stride;
 #ifdef VDR_TUNING
     const bool more = next < n_items && !(p.abl & 2);
@@ -498,272 +529,19 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
 #endif
     if (more) stage_issue(next, smem + (cur ^ 1) * BUF);
     if (computes && do_compute) compute_tile(item, next < n_items ? next : -1, wave, smem + cur * BUF, qf);
+    if (!computes) VDR_STAMP(2);  // (loader / idle wave: its pieces are issued)
     if (more) stage_write(computes && do_compute);
-    cur ^= 1;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------
-// Two-pass persistent variant (129 <= seq <= 208, head dim 64): the S^T tile is never held whole.
-//   The one-pass kernel above keeps all 7 score tiles of a 32-query tile in registers (112 of its 232 VGPRs), which
-//   caps a SIMD at two waves that walk the same phases in step (QK^T, max, exp / P.V): MFMA pipe busy 19 %, the wave's
-//   dependent chain is the launch time.  Here pass 1 computes the score tiles only for the row maximum and drops
-//   them; pass 2 recomputes each tile (4 MFMAs), exponentiates against the final maximum and multiplies by V at once.
-//   +50 % MFMA work (84 instead of 56 per tile-wave: the matrix pipe has the room), the same exponentials, sums and
-//   P.V products in the same order -- results are bitwise those of the one-pass kernels -- at <= 128 VGPRs: four waves
-//   per SIMD, two 7-wave workgroups per CU that drift apart and fill each other's waits.
-//   LDS per workgroup: three rotating images of 208 rows x 128 B (26 KB each; + 2 KB so that the 7th K tile's reads of
-//   rows 208..223 -- keys past the sequence, overwritten with -inf before use -- stay inside the allocation) = 80 KB.
-//   Item n: K_n sits in image kb (loaded during item n-1).  After the top barrier the other two images are free: V_n
-//   goes into kb+1, K_{n+1} into kb+2, both by LDS-DMA, under pass 1 (which reads K only); second barrier; pass 2.
-// -------------------------------------------------------------------------------------------------
-template <int NT>  // query tiles == key tiles == waves: 5 (seq 129..160), 6 (161..192), 7 (193..208)
-__global__ __launch_bounds__(NT * 64, 4) void attn_persist2_kernel(AttnK p, int n_items) {
-  constexpr int ROWS = 208;
-  constexpr int BUFB = ROWS * 128;
-  constexpr int NP = ROWS / 8;                    // 8-row DMA pieces per image
-  constexpr int PPW = (NP + NT - 1) / NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hh = lane >> 5;
-  const int l31 = lane & 31;
-  const int swz = (lane >> 1) & 7;
-  const int HD = p.heads * 64;
-  const float sc = 0.125f * 1.44269504088896341f;
-  const uint32_t ldb = (uint32_t)p.ld_qkv * 2;  // row pitch in bytes
-
-  // lane part of the source address of this wave's DMA pieces (rows past the sequence repeat the last key: finite
-  // values whose P is 0), K swizzle (key >> 1) & 7, V swizzle ((key >> 1) & 1) << 2 -- see attn_persist_kernel
-  uint32_t koff[PPW], voffs[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int r = (wave + i * NT) * 8 + (lane >> 3);
-    const int key = r < p.seq ? r : p.seq - 1;
-    koff[i] = (uint32_t)key * ldb + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-    voffs[i] = (uint32_t)key * ldb + (uint32_t)(((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16);
-  }
-  auto item_base = [&](int item) {  // q of token 0 of (image, head)
-    const int b = item / p.heads;
-    const int hd = item - b * p.heads;
-    return reinterpret_cast<const char*>(p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64);
-  };
-  auto stage_k = [&](const char* base, char* buf) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      if (i < PPW - 1 || wave + i * NT < NP) glds16_raw(base + 2 * HD, koff[i], buf + (wave + i * NT) * 1024);
-  };
-  auto stage_v = [&](const char* base, char* buf) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      if (i < PPW - 1 || wave + i * NT < NP) glds16_raw(base + 4 * HD, voffs[i], buf + (wave + i * NT) * 1024);
-  };
-  int qrow = wave * 32 + l31;
-  qrow = qrow < p.seq ? qrow : p.seq - 1;
-  const uint32_t qoff = (uint32_t)qrow * ldb + hh * 16;
-  auto load_q = [&](const char* base, bf16x8 (&q)[4]) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(base + qoff + ks * 32);
-  };
-
-  const int kx = (hh ^ swz) * 16;  // 16-B chunk (2 ks + hh) ^ swz = (hh ^ swz) ^ 2 ks
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
-  const int vkey = 4 * hh + tq;
-  const int vx = vkey * 128 + 8 * (tp & 1) + ((2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;  // nd: ^ 64
-
-  bf16x8 qf[4], qn[4];
-  auto qk_tile = [&](const char* sK, int kx, int t, f32x16& s) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = 0.0f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * 32 * 128 + (kx ^ (ks * 32)));
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-    }
-    if (t == NT - 1) mask_keys(s, t * 32, hh, p.seq);  // only the last tile can hold keys past the sequence
-  };
-
-  int item = blockIdx.x;
-  if (item >= n_items) return;
-  int kb = 0;
-  {
-    const char* base = item_base(item);
-    stage_k(base, smem);
-    load_q(base, qf);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
-  const int stride = __builtin_amdgcn_readfirstlane(gridDim.x);
-  const bool last_slice = (NT - 1) * 32 + 16 < p.seq;  // second 16-key slice of the last tile holds a valid key
-#ifdef VDR_ATTN_STAMPS
-  int it_no = 0;
-#endif
-  for (; item < n_items; item += stride) {
-#ifdef VDR_ATTN_STAMPS
-    unsigned long long st[16];
-#endif
-    VDR_STAMP(0);
-#ifdef VDR_ATTN_STAMPS
-    st[9] = wall_clock64();  // constant 100 MHz: calibrates the shader clock the other stamps count
-#endif
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // image kb holds K of this item (every wave waited for its pieces); the other two are free
-    asm volatile("" ::: "memory");
-    VDR_STAMP(1);
-    const int vb = kb == 2 ? 0 : kb + 1;
-    const int nb = kb == 0 ? 2 : kb - 1;
-    const int next = item + stride;
-    const bool more = next < n_items;
-    const char* base = item_base(item);
-    const char* nbase = item_base(more ? next : item);
-#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 16)
-    if (it_no == 0)
-#endif
-    {
-      stage_v(base, smem + vb * BUFB);
-      if (more) stage_k(nbase, smem + nb * BUFB);
-    }
-    const char* sK = smem + kb * BUFB + l31 * 128;
-    VDR_STAMP(2);
-
-    // ---- pass 1: row maximum ------------------------------------------------------------------------------------
-    float mx = -INFINITY;
-#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 2)
-    mx = 8.0f;
-#else
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 s;
-      qk_tile(sK, kx, t, s);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
-      asm volatile("" : "+v"(mx));        // this tile's scores are dead here: one tile at a time (VGPR budget)
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#endif
-    // V of this item (and K of the next, and the previous item's output stores) had pass 1 to land
-    asm volatile("" : "+v"(mx));
-    VDR_STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    VDR_STAMP(4);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    VDR_STAMP(5);
-
-    // ---- pass 2: recompute a tile, exponentiate, multiply by V --------------------------------------------------
-    if (more) load_q(nbase, qn);  // lands under pass 2
-    const __attribute__((address_space(3))) char* sV = (const __attribute__((address_space(3))) char*)(smem + vb * BUFB);
-    const float mb = mx * sc;
-    float lsum = 0.0f;
-    f32x16 o[2];
-#pragma unroll
-    for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
-    int kx2 = kx;
-    asm volatile("" : "+v"(kx2));  // opaque: otherwise hipcc keeps pass 1's score tiles (in scratch) instead of recomputing
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x16 s;
-      qk_tile(sK, kx2, t, s);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        // a slice entirely past the sequence carries P = 0: skipped (adds of +0, results unchanged)
-        if (t < NT - 1 || s2 == 0 || last_slice) {
-          bf16x8 pf;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 1)
-            const float pv = fmaf(s[8 * s2 + j], sc, -mb);
-#else
-            const float pv = fast_exp2(fmaf(s[8 * s2 + j], sc, -mb));
-#endif
-#if !(defined(VDR_ATTN_STAMPS) && (VDR_ABL & 8))
-            lsum += pv;
-#endif
-            pf[j] = (bf16_t)pv;
-          }
-#pragma unroll
-          for (int nd = 0; nd < 2; ++nd) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + (t * 32 + s2 * 16) * 128 + (vx ^ (nd * 64))));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + (t * 32 + s2 * 16 + 8) * 128 + (vx ^ (nd * 64))));
-            bf16x8 vf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              vf[j] = lo[j];
-              vf[4 + j] = hi[j];
-            }
-#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 4)
-            asm volatile("" :: "v"(vf), "v"(pf));
-#else
-            o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
-#endif
-          }
-          asm volatile("" : "+v"(lsum));      // the row sum is up to date here: hipcc otherwise parks all exponentials (in scratch) and adds them at the end
-          __builtin_amdgcn_sched_barrier(0);  // keep later slices' work from being hoisted (VGPR budget)
-        }
-      }
-    }
-    const float l = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = wave * 32 + l31;
-    const int b = item / p.heads;
-    const int hd = item - b * p.heads;
-#ifdef VDR_ATTN_STAMPS
-    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
-#endif
-    VDR_STAMP(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next item's Q
     VDR_STAMP(7);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qn[ks]));  // retired by the vmcnt(0) above, BEFORE the stores (see attn_persist_kernel)
-#if defined(VDR_ATTN_STAMPS) && (VDR_ABL & 32)
-    attn_store_row(p, o, inv, q < p.seq && item > n_items, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
-#else
-    attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
-#endif
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    VDR_STAMP(8);
 #ifdef VDR_ATTN_STAMPS
     st[10] = wall_clock64();
-    if (lane == 0 && it_no < 8) {
-      unsigned long long* d = p.stamps + (((size_t)blockIdx.x * NT + wave) * 8 + it_no) * 16;
+    if (lane == 0 && it_no < 16) {
+      unsigned long long* d = p.stamps + (((size_t)blockIdx.x * 8 + wave) * 16 + it_no) * 16;
       for (int i = 0; i < 11; ++i) d[i] = st[i];
     }
     ++it_no;
 #endif
-    kb = nb;
+    cur ^= 1;
   }
-}
-
-template <int NT>
-static hipError_t launch_persist2(const AttnK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = 3 * 208 * 128 + 2048;  // 80 KB: two workgroups per CU
-  auto fn = attn_persist2_kernel<NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  const int n_items = batch * k.heads;
-  const int grid = n_items < 2 * n_cu ? n_items : 2 * n_cu;
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(NT * 64), lds, s, k, n_items);
-  return hipGetLastError();
 }
 
 template <int NT, bool LOADER>
@@ -791,11 +569,12 @@ static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
 
 template <int NT>
 static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)NT * 32 * 128;  // K image + V image
+  constexpr size_t image = 2 * (size_t)NT * 32 * 128;       // K image + V image
+  const size_t lds = image;
   auto fn = attn_kernel<NT>;
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool attr_set = false;  // per instantiation: raised once, not per launch
+  if (image > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)image);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
@@ -814,6 +593,7 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   variant %= 10;
 #else
   k.abl = 0;
+  // 0 library choice, 1 chunked (online softmax), 2 persistent without the loader wave, 3 one-shot, 4 persistent with it
   if (variant < 0 || variant > 4) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
 #endif
   k.qkv = (const bf16_t*)qkv;
@@ -835,10 +615,8 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   }
   k.qt_per_block = nqt;
   k.n_chunks = 1;
-  if ((variant == 2 || variant == 3 || variant == 4 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
+  if ((variant == 2 || variant == 4 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
     // persistent warp-specialised kernel (needs a few items per workgroup to pay off)
-    if (variant == 3 && seq > 128 && seq <= 208)
-      return nqt == 5 ? launch_persist2<5>(k, batch, s) : nqt == 6 ? launch_persist2<6>(k, batch, s) : launch_persist2<7>(k, batch, s);
     if (variant == 4 && seq > 128 && seq <= 224) return launch_persist<7, true>(k, batch, s);
     if (variant == 0 && seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7, true>(k, batch, s);  // nqt <= 7 compute waves
     if (seq > 128 && seq <= 224 && batch * heads >= 512) return launch_persist<7, false>(k, batch, s);
