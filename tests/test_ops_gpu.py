@@ -308,6 +308,29 @@ def test_patch_embed(ops, img, p, D, dt):
     _assert_close(y2[:, 1:].reshape(B * n, D), ref + pos[1:].repeat(B, 1), BF16_EPS, 2e-3, "patch_embed+pos")
 
 
+@pytest.mark.parametrize("img,p,D,B", [(224, 16, 768, 5), (64, 8, 192, 3), (96, 32, 256, 7), (224, 16, 200, 2)])
+def test_patch_embed_gathered_from_images_exact(ops, img, p, D, B):
+    """bf16 images with p in {8, 16, 32} take the im2col-free path (the GEMM's operand loader gathers pixel runs from the
+    NCHW images); integer pixels and weights make the result exact, so every (token, channel, ky, kx) -> operand mapping
+    is pinned bit for bit -- and it must equal the im2col path (fp32 images of the same values) bit for bit as well.
+    Ragged token counts (B * n not a multiple of the 128-row tile), D not a multiple of the tile width."""
+    g = torch.Generator().manual_seed(img * 7 + p)
+    x = torch.randint(-3, 4, (B, 3, img, img), generator=g).float()
+    W = torch.randint(-2, 3, (D, 3, p, p), generator=g).float()
+    b = torch.randint(-3, 4, (D,), generator=g).float()
+    n = (img // p) ** 2
+    ref = torch.nn.functional.conv2d(x, W, b, stride=p).flatten(2).transpose(1, 2).reshape(B * n, D)
+    assert ref.abs().max() < 16384  # (bf16 output: compare after the same rounding)
+    y = ops.patch_embed(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), p)
+    assert torch.equal(y.float().cpu(), _bf(ref).float()), f"gathered patch embed {img}/{p}"
+    y_col = ops.patch_embed(x.cuda(), W.bfloat16().cuda(), b.cuda(), p)  # fp32 images: im2col + GEMM
+    assert torch.equal(y, y_col)
+    pos = torch.randint(-2, 3, (n + 1, D), generator=g).float()
+    y2 = ops.patch_embed(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), p, pos=pos.cuda(), row_stride=n + 1, row_offset=1)
+    y2 = y2.float().cpu().reshape(B, n + 1, D)
+    assert torch.equal(y2[:, 1:].reshape(B * n, D), _bf(ref + pos[1:].repeat(B, 1)).float())
+
+
 # ---- SAM / MedSAM attention with decomposed relative position bias ------------------------------------
 def _relpos_attn_ref(qkv, rel_h, rel_w, B, S, H):
     from oracle import sam_oracle as so

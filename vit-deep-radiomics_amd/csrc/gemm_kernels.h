@@ -417,13 +417,25 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
 
   const bf16_t* a_src[NA4];
   const bf16_t* b_src[NB];
+  // im2col-free patchify (EPI_PATCH, p.pg_ps != 0): row = token (b, py, px), the 16-byte chunk c of 64-deep piece 0 is
+  // pixels kx0 .. kx0+7 of patch row ky = 8c / p of channel 0; piece pc adds a wave-uniform offset (see stage_a)
+  const bool patch_gather = EPI == EPI_PATCH && __builtin_amdgcn_readfirstlane(p.pg_ps) != 0;
 #pragma unroll
   for (int q = 0; q < NA4; ++q) {
     const int r = (wave * NA4 + q) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int64_t gr = m0 + r;
     gr = gr < p.M ? gr : p.M - 1;
-    a_src[q] = p.A + gr * p.lda + c * 8;
+    if (patch_gather) {
+      const int P = 1 << p.pg_ps, G = p.pg_g, side = G << p.pg_ps;
+      const int b = (int)(gr / (G * G));
+      const int t = (int)(gr - (int64_t)b * (G * G));
+      const int py = t / G, px = t - py * G;
+      const int ky = (c * 8) >> p.pg_ps, kx0 = (c * 8) & (P - 1);
+      a_src[q] = p.A + ((int64_t)b * p.pg_C * side + py * P + ky) * side + px * P + kx0;
+    } else {
+      a_src[q] = p.A + gr * p.lda + c * 8;
+    }
   }
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
@@ -454,8 +466,19 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
   const int nsteps = p.K >> 5;  // even: K % 64 == 0
   const bool do_epi = !VDR_ABL(p, 1);
   const bool skip_loads = VDR_ABL(p, 4);
+  int a_piece = 0;  // (patch gather) 64-deep piece the next stage_a fetches
   auto stage_a = [&](int aslot) {
     char* d = smem + aslot * APIECE;
+    if (patch_gather) {
+      // k = 64 a_piece .. + 63: channel k / p^2, first patch row (k % p^2) / p -- the same for every lane (p^2 % 64 == 0)
+      const int kq = a_piece << 6, side = p.pg_g << p.pg_ps;
+      const int ch = kq >> (2 * p.pg_ps), kyb = (kq & ((1 << (2 * p.pg_ps)) - 1)) >> p.pg_ps;
+      const int64_t off = ((int64_t)ch * side + kyb) * side;
+#pragma unroll
+      for (int q = 0; q < NA4; ++q) glds16(a_src[q] + off, d + (wave * NA4 + q) * 1024);
+      ++a_piece;
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NA4; ++q) {
       glds16(a_src[q], d + (wave * NA4 + q) * 1024);
@@ -669,6 +692,15 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.a_gs = a.a_gs;
   k.a_is = a.a_is;
   k.out_f32 = a.out_f32;
+  if (a.patch_p) {
+    const int P = a.patch_p;
+    if (epi != EPI_PATCH || PIPE < 50 || PIPE >= 60 || (P != 8 && P != 16 && P != 32) || a.patch_g <= 0 || a.patch_C <= 0 || a.K != a.patch_C * P * P ||
+        a.M % ((int64_t)a.patch_g * a.patch_g) || a.a_rpg || ((uintptr_t)a.A & 15))
+      return hipErrorInvalidValue;
+    k.pg_ps = P == 8 ? 3 : P == 16 ? 4 : 5;
+    k.pg_g = a.patch_g;
+    k.pg_C = a.patch_C;
+  }
   {
     VDR_KNOB int nt_env = tuning_env("VDR_GEMM_NT", -1);
     const bool big = (double)a.M * (double)a.ldc * 2.0 >= 128e6 && !a.resid;  // write-once output larger than half the Infinity Cache

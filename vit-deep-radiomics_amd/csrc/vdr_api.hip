@@ -575,6 +575,12 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   return 26;
 }
 
+// im2col-free patchify (GemmArgs::patch_p): bf16 NCHW images, 16-byte aligned, patch side 8 / 16 / 32, a ring4 tile variant
+bool patch_gather_ok(int in_dtype, int patch, int variant, const void* images) {
+  return in_dtype == VDR_BF16 && (patch == 8 || patch == 16 || patch == 32) && variant >= 26 && variant <= 28 &&
+         ((uintptr_t)images & 15) == 0;
+}
+
 struct LnFold {
   const float* stats = nullptr;   // consumer: (mean, rstd) per row
   const float* colsum = nullptr;  // consumer: column sums of the folded weight
@@ -1260,14 +1266,24 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     hipStream_t s = ns == 1 ? caller : m->streams[si];
     const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* img = (const char*)images + (size_t)b0 * img_elems * in_es;
-    {
+    // bf16 images with a patch side of 8 / 16 / 32: the patch GEMM's operand loader gathers 16-byte runs of pixels
+    // straight from the NCHW images (ring4 tile variants) -- no col buffer, no im2col launch.  fp32 images (the loader
+    // is an LDS-DMA: it cannot convert) and p = 14 (runs of 14 pixels are not 16-byte chunks) go through im2col.
+    const int pvar = gemm_variant_for(VDR_K_GEMM_PATCH, (int64_t)mb * n, D);
+    const bool fused_patch = patch_gather_ok(in_dtype, c.patch, pvar, img);
+    if (!fused_patch) {
       Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)mb * img_elems * in_es + 2.0 * mb * n * m->Kp);
       VDR_TRY(launch_im2col(img, in_dtype == VDR_BF16, w.u, mb, c.in_chans, c.img, c.patch, m->Kp, s), "im2col");
     }
     const bool pe_only = out_mode == VDR_OUT_PATCH_EMBED;
     {
       GemmArgs g{};
-      g.A = w.u;
+      g.A = fused_patch ? (const void*)img : (const void*)w.u;
+      if (fused_patch) {
+        g.patch_p = c.patch;
+        g.patch_g = c.img / c.patch;
+        g.patch_C = c.in_chans;
+      }
       g.W = m->w_patch;
       g.bias = m->b_patch;
       g.pos = pe_only ? nullptr : m->pos;
@@ -1294,7 +1310,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       }
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
-      VDR_TRY(launch_gemm_w(m, g, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, g.M, g.N), s), "patch gemm");
+      VDR_TRY(launch_gemm_w(m, g, EPI_PATCH, pvar, s), "patch gemm");
     }
     if (pe_only) continue;
     if (c.window > 0) {
@@ -1643,9 +1659,16 @@ int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const fl
   int rc = check_device(nullptr);
   if (rc) return rc;
   const int g = img / p, n = g * g, Kp = round_up(C * p * p, 64);
-  OP_TRY(launch_im2col(images, in_dtype == VDR_BF16, col, batch, C, img, p, Kp, (hipStream_t)stream), "im2col");
+  const int variant = gemm_variant_for(VDR_K_GEMM_PATCH, (int64_t)batch * n, D);
+  const bool fused = patch_gather_ok(in_dtype, p, variant, images);  // (see vdr_forward: no im2col pass, `col` untouched)
+  if (!fused) OP_TRY(launch_im2col(images, in_dtype == VDR_BF16, col, batch, C, img, p, Kp, (hipStream_t)stream), "im2col");
   GemmArgs a{};
-  a.A = col;
+  a.A = fused ? images : col;
+  if (fused) {
+    a.patch_p = p;
+    a.patch_g = g;
+    a.patch_C = C;
+  }
   a.W = W;
   a.bias = bias;
   a.pos = pos;
@@ -1658,7 +1681,7 @@ int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const fl
   a.ldc = D;
   a.ldr = D;
   a.omap = RowMap{n, row_stride, row_offset};
-  OP_TRY(launch_gemm(a, EPI_PATCH, gemm_variant_for(VDR_K_GEMM_PATCH, a.M, a.N), (hipStream_t)stream), "patch gemm");
+  OP_TRY(launch_gemm(a, EPI_PATCH, variant, (hipStream_t)stream), "patch gemm");
   return VDR_OK;
 }
 

@@ -58,7 +58,10 @@ struct GemmArgs {
   // (a_rpg = 0: plain m * lda).  Used to read the per-head q slices of a packed qkv activation as rows.
   int a_rpg = 0;
   int64_t a_gs = 0, a_is = 0;
-  int out_f32 = 0;  // C is fp32 (EPI_BIAS only)
+  int out_f32 = 0;  // C is fp32 (EPI_BIAS / EPI_PATCH)
+  // im2col-free patchify (EPI_PATCH on the ring4 variants): A = bf16 NCHW images [B, C, g*p, g*p], M = B*g*g tokens,
+  // K = C*p*p with p in {8, 16, 32}; the operand loader gathers 16-byte runs of pixels straight from the images
+  int patch_p = 0, patch_g = 0, patch_C = 0;
   // MX-fp8 GEMM (launch_gemm_mx): A and W are e4m3 payloads, *_scale their e8m0 scale arrays (mx.hip layout)
   const void* a_scale = nullptr;
   const void* w_scale = nullptr;
