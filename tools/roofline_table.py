@@ -8,7 +8,7 @@ PEAK_TF, PEAK_GBS = 2500.0, 8000.0  # MI355X_MICROARCH.md: dense bf16 MFMA, HBM3
 HBM_CLASSES = {"im2col", "layernorm", "final_ln", "assemble"}
 NOTE = {"gemm_fc1": "mlp.fc1 + erf-GELU (LayerNorm folded in)", "gemm_fc2": "mlp.fc2 + residual (+ LN partial sums)",
         "gemm_qkv": "attn.qkv (LayerNorm folded in)", "gemm_proj": "attn.proj + residual (+ LN partial sums)",
-        "attention": "softmax(q k^T / 8) v, 3072 heads of 197 x 64", "gemm_patch": "patchify conv as im2col GEMM + cls/pos",
+        "attention": "softmax(q k^T / 8) v, 3072 heads of 197 x 64", "gemm_patch": "patchify conv as a GEMM (bf16 images: pixels gathered by the operand loader) + cls/pos",
         "im2col": "image -> patch rows", "layernorm": "ln_finalize: (sum, sumsq) partials -> (mean, rstd)",
         "final_ln": "final LayerNorm of the CLS rows -> fp32 out", "assemble": "cls row + stats of the token buffer"}
 
