@@ -316,7 +316,8 @@ int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float
  * the op called at tfds_dense_descriptor.py:128.
  *   images NCHW [batch, C, img, img] in_dtype; W bf16 [D, Kp] (C*p*p columns zero-padded to
  *   Kp = roundup(C*p*p, 64)); bias fp32 [D]; pos fp32 [n(+1), D] or NULL;
- *   col: device scratch of batch*n*Kp bf16;
+ *   col: device scratch of batch*n*Kp bf16 (left untouched when the images are bf16, 16-byte aligned and p is 8, 16
+ *   or 32: the GEMM then gathers its operand from the images, no im2col pass);
  *   y bf16: row (b*row_stride + row_offset + i) for patch i of image b, plus pos[row_offset+i]. */
 int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const float* bias,
                        const float* pos, void* col, void* y, int batch, int C, int img, int p, int D,

@@ -61,6 +61,9 @@ struct GemmK {
   // im2col-free patchify (ring4, EPI_PATCH): A is a bf16 NCHW image batch and row m / column k of the GEMM operand are
   // token (b, py, px) / (channel, ky, kx) of Conv2d(C, D, p, stride p); pg_ps = log2(p) (p in {8, 16, 32}), 0 = off
   int pg_ps = 0, pg_g = 0, pg_C = 0;
+#ifdef VDR_GEMM_STAMPS
+  unsigned long long* stamps = nullptr;  // tools/micro/gemm_stamps.hip: [workgroup][wave][8] s_memtime / s_memrealtime stamps
+#endif
   int abl = 0;  // tuning builds: ablation bits, 1 = skip the epilogue, 4 = skip global loads after the first units, 8 = skip the output stores
 };
 

@@ -414,6 +414,14 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+#ifdef VDR_GEMM_STAMPS
+  unsigned long long st[8];
+  st[0] = __builtin_readcyclecounter();
+  st[6] = wall_clock64();
+#define VDR_GSTAMP(i) st[i] = __builtin_readcyclecounter()
+#else
+#define VDR_GSTAMP(i)
+#endif
 
   const bf16_t* a_src[NA4];
   const bf16_t* b_src[NB];
@@ -534,9 +542,11 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
     my_stats.x = (float)mean;
     my_stats.y = (float)(1.0 / sqrt(var + (double)p.ln_eps));
   }
+  VDR_GSTAMP(1);  // addresses computed, ring fill issued
   if (nsteps > 2) wait_vmcnt<NB + NA4 + NB>();
   else wait_vmcnt<NB>();
   __builtin_amdgcn_s_barrier();
+  VDR_GSTAMP(2);  // first units landed
 #pragma unroll
   for (int j = 0; j < 4; ++j) fb[j] = ld(b_base + j * 1024);
 #pragma unroll
@@ -594,7 +604,15 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
   }
 
   if (!do_epi && acc.t[0][0][0] != 12345.678f) return;  // ablation (tuning builds): no epilogue, accumulators stay live
+#ifdef VDR_GEMM_STAMPS
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc.t[j][i]));
+#endif
+  VDR_GSTAMP(3);  // main loop done (accumulators complete)
   __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
+  VDR_GSTAMP(4);
   constexpr int STATS_OFF = NW * 32 * 272;  // behind the wave-private staging images
   if (p.ln_cpart) {
     if (tid < BM) reinterpret_cast<float2*>(smem + STATS_OFF)[tid] = my_stats;
@@ -602,6 +620,16 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
   }
   epilogue_tile<EPI>(p, acc, smem, wave, m0 + wm * 64, n0 + wn * 64, lane,
                      p.ln_cpart ? reinterpret_cast<const float2*>(smem + STATS_OFF) + wm * 64 : nullptr);
+#ifdef VDR_GEMM_STAMPS
+  asm volatile("" ::: "memory");
+  VDR_GSTAMP(5);  // epilogue instructions issued (stores may still be in flight)
+  st[7] = wall_clock64();
+  if (lane == 0 && p.stamps) {
+    unsigned long long* d = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+    for (int i = 0; i < 8; ++i) d[i] = st[i];
+  }
+#endif
+#undef VDR_GSTAMP
 }
 
 template <int WAVES_M, int WAVES_N, int EPI>
@@ -624,6 +652,9 @@ static auto launch_pick() -> void (*)(GemmK) {
     return gemm_ring3_kernel<WAVES_M, WAVES_N, PIPE - 30, E>;
 }
 
+#ifdef VDR_GEMM_STAMPS
+inline unsigned long long* g_gemm_stamps = nullptr;  // tools/micro/gemm_stamps.hip
+#endif
 inline int g_gemm_ablation = 0;  // tuning builds only (variant / 100 of vdr_op_linear)
 inline int g_gemm_gn = -1;       // tuning builds only: column-group width override (variant / 1000 - 1)
 
@@ -694,7 +725,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.out_f32 = a.out_f32;
   if (a.patch_p) {
     const int P = a.patch_p;
-    if (epi != EPI_PATCH || PIPE < 50 || PIPE >= 60 || (P != 8 && P != 16 && P != 32) || a.patch_g <= 0 || a.patch_C <= 0 || a.K != a.patch_C * P * P ||
+    if (epi != EPI_PATCH || PIPE != 50 || (P != 8 && P != 16 && P != 32) || a.patch_g <= 0 || a.patch_C <= 0 || a.K != a.patch_C * P * P ||
         a.M % ((int64_t)a.patch_g * a.patch_g) || a.a_rpg || ((uintptr_t)a.A & 15))
       return hipErrorInvalidValue;
     k.pg_ps = P == 8 ? 3 : P == 16 ? 4 : 5;
@@ -720,6 +751,9 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     k.ln_eps = a.ln_eps;
   }
   k.abl = g_gemm_ablation;
+#ifdef VDR_GEMM_STAMPS
+  k.stamps = g_gemm_stamps;
+#endif
   if (PIPE >= 50 && a.a_rpg) return hipErrorInvalidValue;  // the two-stride A gather stays on ring3
 
   const dim3 grid((unsigned)k.nwg), block(NWV * 64);
