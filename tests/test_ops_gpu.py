@@ -289,7 +289,9 @@ def test_attention_softmax_is_shift_invariant_and_rows_sum_to_one(ops):
 # ---- patch embed ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("img,p,D,dt", [(224, 16, 192, torch.float32), (224, 16, 768, torch.bfloat16),
                                         (56, 14, 384, torch.float32), (84, 14, 128, torch.bfloat16),
-                                        (32, 8, 64, torch.float32)])
+                                        (32, 8, 64, torch.float32),
+                                        # 37 patches per row: the LDS im2col's second workgroup of a row holds 5 of 32
+                                        (518, 14, 64, torch.float32), (518, 14, 64, torch.bfloat16)])
 def test_patch_embed(ops, img, p, D, dt):
     g = torch.Generator().manual_seed(img + D)
     B = 3
@@ -329,6 +331,22 @@ def test_patch_embed_gathered_from_images_exact(ops, img, p, D, B):
     y2 = ops.patch_embed(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), p, pos=pos.cuda(), row_stride=n + 1, row_offset=1)
     y2 = y2.float().cpu().reshape(B, n + 1, D)
     assert torch.equal(y2[:, 1:].reshape(B * n, D), _bf(ref + pos[1:].repeat(B, 1)).float())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_patch_embed_p14_exact(ops, dt):
+    """p = 14 (DINOv2 / ViT-L/14 / ViT-g/14) goes through the LDS im2col (coalesced pixel pairs scattered into [patch][K]
+    rows, K padded 588 -> 640 with zeros): integer data pins every pixel's place exactly, for both pixel types, with a
+    ragged last workgroup per patch row (37 = 32 + 5) and more than one image."""
+    g = torch.Generator().manual_seed(14)
+    B, img, p, D = 2, 518, 14, 72
+    x = torch.randint(-3, 4, (B, 3, img, img), generator=g).float()
+    W = torch.randint(-2, 3, (D, 3, p, p), generator=g).float()
+    b = torch.randint(-3, 4, (D,), generator=g).float()
+    n = (img // p) ** 2
+    ref = torch.nn.functional.conv2d(x, W, b, stride=p).flatten(2).transpose(1, 2).reshape(B * n, D)
+    y = ops.patch_embed(x.to(dt).cuda(), W.bfloat16().cuda(), b.cuda(), p)
+    assert torch.equal(y.float().cpu(), _bf(ref).float())
 
 
 # ---- SAM / MedSAM attention with decomposed relative position bias ------------------------------------

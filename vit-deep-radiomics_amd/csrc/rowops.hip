@@ -212,9 +212,91 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ im
   *reinterpret_cast<bf16x8*>(col + row * Kp + kk) = o;
 }
 
+// The same matrix for patch sides that are not a multiple of 8 (p = 14: DINOv2, ViT-L/14, ViT-g/14), through LDS: a
+// workgroup takes up to 32 neighbouring patches of one patch row -- in the image that is C*p runs of 32*p contiguous
+// pixels, read as coalesced pairs (p even: a pair never straddles two patches), converted and scattered into an LDS
+// image [patch][Kp] (row stride Kp*2 + 32 bytes: consecutive patches start 8 banks apart) -- and writes the rows out as
+// whole 16-byte chunks.  (The direct kernel above needs 8 scalar loads and 8 index divisions per 16-byte store here:
+// 2.0 TB/s of pixels + rows in the reference's dinov2 mode; this form: see DESIGN.md §6 f-2.)
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const void* __restrict__ images, bf16_t* __restrict__ col, int C,
+                                                          int img, int p, int g, int Kp, int tpb, int blocks_per_row) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int RS = Kp * 2 + 32;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int xb = bid % blocks_per_row;
+  bid /= blocks_per_row;
+  const int py = bid % g;
+  const int b = bid / g;
+  const int t0 = xb * tpb;
+  const int nt = min(tpb, g - t0);  // patches of this workgroup
+  const int pp = p * p, Kreal = C * pp;
+  // zero the K padding
+  const int padw = (Kp - Kreal) >> 1;  // dwords per row (Kreal and Kp are even)
+  for (int i = tid; i < nt * padw; i += 256) {
+    const int r = i / padw, j = i - r * padw;
+    *reinterpret_cast<uint32_t*>(smem + r * RS + (Kreal + 2 * j) * 2) = 0u;
+  }
+  // pixels: a thread owns pixel pair j of the workgroup's run (its patch and kx fixed once) and walks the C*p image rows
+  const int ppr = (nt * p) >> 1;
+  const int64_t img_base = ((int64_t)b * C * img + py * p) * img + t0 * p;
+  for (int j = tid; j < ppr; j += 256) {
+    const int x = 2 * j;
+    const int t = x / p, kx = x - t * p;
+    char* dst = smem + t * RS + kx * 2;
+    auto load = [&](int64_t src) {
+      bf16x2 v;
+      if (IN_BF16) {
+        v = *reinterpret_cast<const bf16x2*>((const bf16_t*)images + src);
+      } else {
+        const float2 f = *reinterpret_cast<const float2*>((const float*)images + src);
+        v[0] = (bf16_t)f.x;
+        v[1] = (bf16_t)f.y;
+      }
+      return v;
+    };
+    for (int c = 0; c < C; ++c) {
+      const int64_t src = img_base + (int64_t)c * img * img + x;
+      char* d = dst + c * pp * 2;
+      int ky = 0;
+      for (; ky + 7 <= p; ky += 7) {  // 7 rows in flight (p = 14: two rounds)
+        bf16x2 v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) v[u] = load(src + (int64_t)(ky + u) * img);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) *reinterpret_cast<bf16x2*>(d + (ky + u) * p * 2) = v[u];
+      }
+      for (; ky < p; ++ky) *reinterpret_cast<bf16x2*>(d + ky * p * 2) = load(src + (int64_t)ky * img);
+    }
+  }
+  __syncthreads();
+  const int k8 = Kp >> 3;
+  const int64_t row0 = ((int64_t)b * g + py) * g + t0;
+  for (int i = tid; i < nt * k8; i += 256) {
+    const int r = i / k8, ch = i - r * k8;
+    *reinterpret_cast<bf16x8*>(col + (row0 + r) * Kp + ch * 8) = *reinterpret_cast<const bf16x8*>(smem + r * RS + ch * 16);
+  }
+}
+
 hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,
                          int Kp, hipStream_t s) {
   if (batch <= 0 || p <= 0 || img % p || (Kp & 63) || Kp < C * p * p) return hipErrorInvalidValue;
+  if ((p & 7) && !(p & 1) && !(img & 1) && (((uintptr_t)images) & 7) == 0) {
+    // even patch side that is not a multiple of 8: the LDS form
+    const int g = img / p;
+    const int tpb = g < 32 ? g : 32;
+    const int bpr = (g + tpb - 1) / tpb;
+    const size_t lds = (size_t)tpb * (Kp * 2 + 32);
+    if (lds <= 65536) {
+      const dim3 grid((unsigned)((int64_t)batch * g * bpr)), block(256);
+      if (in_bf16)
+        hipLaunchKernelGGL((im2col_rows_kernel<true>), grid, block, lds, s, images, (bf16_t*)col, C, img, p, g, Kp, tpb, bpr);
+      else
+        hipLaunchKernelGGL((im2col_rows_kernel<false>), grid, block, lds, s, images, (bf16_t*)col, C, img, p, g, Kp, tpb, bpr);
+      return hipGetLastError();
+    }
+  }
   // the fast path reads 8 pixels with vector loads: needs p % 8 == 0 and img % 8 == 0 so that every
   // 8-pixel run starts 16-byte aligned (the image base is assumed 16-byte aligned)
   const int g = img / p;
