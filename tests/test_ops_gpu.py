@@ -153,6 +153,25 @@ def test_linear_many_tiles_exact(ops):
             assert torch.equal(y.float().cpu(), x @ W.t() + b), (M, N, K, v)
 
 
+def test_linear_persistent_residual_epilogue_exact(ops):
+    """More tiles than the chip holds workgroups (two per CU) and the residual epilogue: ring4 then runs its persistent
+    form -- resident workgroups striding over the tile list, the argument block re-read per tile.  Integer data: exact,
+    every row, ragged last tile row and a partial last stride; and bitwise equal to the one-tile-per-workgroup kernels
+    (ring3, which has no persistent form)."""
+    from vdr import EPI_BIAS_RESID
+    g = torch.Generator().manual_seed(29)
+    for (M, N, K) in [(30011, 768, 128), (50432, 768, 192), (9000, 3000, 64)]:
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-3, 4, (N,), generator=g).float()
+        r = torch.randint(-4, 5, (M, N), generator=g).float()
+        Wd = _bf(W).cuda()
+        y = ops.linear(_bf(x).cuda(), ops.pack_linear_weight(Wd), b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=26, packed=True)
+        assert torch.equal(y.float().cpu(), x @ W.t() + b + r), (M, N, K)
+        y3 = ops.linear(_bf(x).cuda(), Wd, b.cuda(), resid=_bf(r).cuda(), epilogue=EPI_BIAS_RESID, variant=22)
+        assert torch.equal(y, y3)
+
+
 SHAPES = [(197 * 3, 768, 768), (197 * 2 + 5, 2304, 768), (300, 3072, 768), (260, 768, 3072), (197, 192, 192),
           (1000, 576, 192), (64, 1024, 1024), (257 * 2, 1536, 1536)]
 

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring3_kernel(Ge
 // Issue schedule (after the mid-step barrier of step s): W unit s+3 every step, A piece (s+3)/2 on odd steps; the
 // counted vmcnt of step s leaves exactly what step s-1 issued in flight (NB, plus NA4 when s is even).
 // -------------------------------------------------------------------------------------------------
-template <int WAVES_M, int WAVES_N, int EPI>
+template <int WAVES_M, int WAVES_N, int EPI, bool OPAQUE_TID = false>
 VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, char* smem) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * 64;
@@ -410,7 +410,8 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
   constexpr int NB = BN / 16 / NW;   // per wave per W unit (16 rows x 64 B each = 8 row pairs x 128 B)
   static_assert(BM % (8 * NW) == 0 && BN % (16 * NW) == 0, "tile/wave mismatch");
 
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  if (OPAQUE_TID) asm volatile("" : "+v"(tid));  // (persistent form: keeps the lane-derived addresses from being hoisted out of the tile loop)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -641,6 +642,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4_kernel(Ge
   gemm_ring4_body<WAVES_M, WAVES_N, EPI>(p, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
 }
 
+// Persistent form of ring4: as many workgroups as the chip holds at once (two per CU), each walking the tile list with
+// that stride.  A workgroup slot is held until its last output store has drained and a fresh workgroup has been
+// launched into it -- stamped (tools/micro/gemm_stamps.hip): the 512 slots are occupied 81-85 % of a launch -- and the
+// loop saves the relaunch.  Measured at M = 50432 (tools/kbench.py in alternating processes, VDR_GEMM_PERSISTENT=0 / 1):
+// fc2 243 -> 235 us, proj 83 -> 82; whole ViT-B forward 10.515 -> 10.445 ms (tools/ab_forward.py).  It is no more than
+// that because the next tile's counted vmcnt waits sit out the drain of the previous tile's stores all the same (vmcnt
+// retires in issue order), and qkv / fc1 LOSE 4-6 % (6-10 VGPRs of their epilogue spill in the loop form): used for the
+// residual epilogue only.  Two things made an earlier attempt lose 13 %: (i) kept live across the loop, the ~75 SGPRs of the
+// argument block and everything loop-invariant derived from them spill (100 SGPRs, 29 VGPRs to scratch) -- the block is
+// re-read per tile through the kernarg pointer made opaque; (ii) hipcc hoists the lane-derived addresses of the body out
+// of the loop (+20 VGPRs at a 128-register budget) -- the body takes an opaque copy of threadIdx.x.
+template <int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(GemmK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef const __attribute__((address_space(4))) GemmK* kernarg_ptr;
+  kernarg_ptr pk = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();  // (p is the only argument)
+  const int nwg = p.nwg, stride = gridDim.x;
+  for (int id = blockIdx.x; id < nwg; id += stride) {
+    asm volatile("" : "+s"(pk));
+#ifdef __HIP_DEVICE_COMPILE__
+    GemmK q;
+    {
+      constexpr int NWORDS = sizeof(GemmK) / 4;
+      uint32_t w[NWORDS];
+      const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)pk;
+#pragma unroll
+      for (int i = 0; i < NWORDS; ++i) w[i] = src[i];
+      __builtin_memcpy(&q, w, sizeof(GemmK));
+    }
+#else
+    const GemmK q = p;
+#endif
+    const int wg = xcd_remap(id, nwg);
+    int tm, tn;
+    tile_of(q, wg, tm, tn);
+    gemm_ring4_body<WAVES_M, WAVES_N, EPI, true>(q, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is read out: the next tile's ring fill may overwrite it
+    __syncthreads();
+  }
+}
+
 // PIPE: 3x = ring3 with x LDS slots, 4x = ring3k with x super-slots, 50 = ring4
 template <int WAVES_M, int WAVES_N, int PIPE, int E>
 static auto launch_pick() -> void (*)(GemmK) {
@@ -655,6 +697,17 @@ static auto launch_pick() -> void (*)(GemmK) {
 #ifdef VDR_GEMM_STAMPS
 inline unsigned long long* g_gemm_stamps = nullptr;  // tools/micro/gemm_stamps.hip
 #endif
+// the persistent form exists for the residual epilogue of ring4 (tuning builds: for every epilogue, variant 2xx)
+template <int WAVES_M, int WAVES_N, int PIPE, int E>
+static auto launch_pick_persistent() -> void (*)(GemmK) {
+#ifdef VDR_TUNING
+  if constexpr (PIPE >= 50) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E>;
+#else
+  if constexpr (PIPE >= 50 && E == EPI_BIAS_RESID) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E>;
+#endif
+  return launch_pick<WAVES_M, WAVES_N, PIPE, E>();
+}
+
 inline int g_gemm_ablation = 0;  // tuning builds only (variant / 100 of vdr_op_linear)
 inline int g_gemm_gn = -1;       // tuning builds only: column-group width override (variant / 1000 - 1)
 
@@ -756,7 +809,15 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 #endif
   if (PIPE >= 50 && a.a_rpg) return hipErrorInvalidValue;  // the two-stride A gather stays on ring3
 
-  const dim3 grid((unsigned)k.nwg), block(NWV * 64);
+  dim3 grid((unsigned)k.nwg), block(NWV * 64);
+  bool persistent = PIPE >= 50 && epi == EPI_BIAS_RESID;  // (see gemm_ring4p_kernel)
+#ifdef VDR_TUNING
+  {
+    VDR_KNOB int pers_env = tuning_env("VDR_GEMM_PERSISTENT", -1);
+    if (pers_env >= 0) persistent = persistent && pers_env;
+    if ((k.abl & 2) && PIPE >= 50) persistent = true;
+  }
+#endif
   const size_t staging = (size_t)WAVES_M * WAVES_N * 32 * 272;  // epilogue images (ring3 / ring4: one per wave)
   size_t lds;
   if (PIPE >= 50) {
@@ -777,12 +838,32 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 #define VDR_LAUNCH(E)                                                                                  \
   case E: {                                                                                            \
     auto fn = launch_pick<WAVES_M, WAVES_N, PIPE, E>();                                                \
-    static size_t lds_set = 0; /* per instantiation: the attribute is raised once, not per launch */   \
-    if (lds > 65536 && lds > lds_set) {                                                                \
+    if (persistent && launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>() != fn) {                     \
+      auto pfn = launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>();                                  \
+      static int slots = 0; /* workgroups of this instantiation the chip holds at once */              \
+      if (!slots) {                                                                                    \
+        int dev = 0, per_cu = 0;                                                                       \
+        hipDeviceProp_t prop;                                                                          \
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||    \
+            hipFuncSetAttribute((const void*)pfn, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                                (int)(lds > 65536 ? lds : 65536)) != hipSuccess ||                     \
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pfn, (int)block.x, lds) != hipSuccess || \
+            per_cu <= 0)                                                                               \
+          return hipErrorUnknown;                                                                      \
+        slots = per_cu * prop.multiProcessorCount;                                                     \
+      }                                                                                                \
+      if (k.nwg > slots) {                                                                             \
+        fn = pfn;                                                                                      \
+        grid = dim3((unsigned)slots);                                                                  \
+      }                                                                                                \
+    }                                                                                                  \
+    static size_t lds_set[2] = {0, 0}; /* per kernel: the attribute is raised once, not per launch */  \
+    size_t& lset = lds_set[grid.x != (unsigned)k.nwg];                                                 \
+    if (lds > 65536 && lds > lset) {                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                          (int)lds);                                                    \
       if (e != hipSuccess) return e;                                                                   \
-      lds_set = lds;                                                                                   \
+      lset = lds;                                                                                      \
     }                                                                                                  \
     hipLaunchKernelGGL(fn, grid, block, lds, s, k);                                                    \
     break;                                                                                             \
