@@ -570,8 +570,8 @@ int gemm_variant_for(int cls, int64_t M = 1 << 30, int N = 1 << 30) {
   if (o >= 0) return o;
   // ring4 (whole-line operand staging: packed weights + 64-deep activation pieces), 128x256 tile, 8 waves, two
   // workgroups per CU.  Measured at M = 50432, interleaved rounds in one process, weights packed in both arms
-  // (tools/kbench.py): against ring3 128x256 qkv 0.195 -> 0.184 ms, proj 0.098 -> 0.075, fc1 0.290 -> 0.276, fc2
-  // 0.249 -> 0.221; the 256x256 forms (ring3 23, ring4 27) lose on every shape.
+  // (tools/kbench.py, alternating order): against ring3 128x256 qkv 0.181 -> 0.176 ms, proj 0.086 -> 0.078, fc1
+  // 0.267 -> 0.257, fc2 0.246 -> 0.230; the 256x256 forms (ring3 23, ring4 27) lose on every shape.
   return 26;
 }
 
