@@ -8,9 +8,9 @@ import sys
 from collections import defaultdict
 
 CLASSES = [  # (label, regex on the demangled kernel name)
-    ("gemm_fc1 (EPI_BIAS_GELU)", r"gemm_ring\d_kernel<[^>]*, 1>"),
-    ("gemm_proj+fc2 (EPI_BIAS_RESID)", r"gemm_ring\d_kernel<[^>]*, 2>"),
-    ("gemm_qkv (EPI_BIAS)", r"gemm_ring\d_kernel<[^>]*, 0>"),
+    ("gemm_fc1 (EPI_BIAS_GELU)", r"gemm_ring\dp?_kernel<[^>]*, 1>"),
+    ("gemm_proj+fc2 (EPI_BIAS_RESID)", r"gemm_ring\dp?_kernel<[^>]*, 2>"),
+    ("gemm_qkv (EPI_BIAS)", r"gemm_ring\dp?_kernel<[^>]*, 0>"),
     ("attention", r"attn_(persist_)?kernel"),
     ("ln_finalize", r"ln_finalize_kernel"),
 ]
