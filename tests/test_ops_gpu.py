@@ -271,6 +271,20 @@ def test_attention_single_chunk(ops, B, N, H):
     _assert_close(o, ref, 2 * BF16_EPS, 6e-3, f"attention B{B} N{N} H{H}")
 
 
+@pytest.mark.parametrize("B,N,H", [(43, 197, 12), (2, 129, 3), (3, 224, 2), (5, 160, 1), (1, 193, 7)])
+def test_attention_persistent_kernels_match_one_shot_bitwise(ops, B, N, H):
+    """Sequences of 129..224 tokens have three single-chunk kernels: one workgroup per (image, head) (variant 3), the
+    persistent kernel (2) and the persistent kernel with its loader wave (4; the library's choice from 512 items on --
+    (43, 197, 12) is 516).  Same arithmetic in the same order: bitwise equal, and within bf16 of the fp32 reference."""
+    g = torch.Generator().manual_seed(B * 131 + N)
+    qkv = _bf(torch.randn(B * N, 3 * H * 64, generator=g))
+    ref = _attn_ref(qkv, B, N, H)
+    outs = {v: ops.attention(qkv.cuda(), B, N, H, variant=v) for v in (3, 2, 4, 0)}
+    for v in (2, 4, 0):
+        assert torch.equal(outs[v], outs[3]), f"variant {v} B{B} N{N} H{H}"
+    _assert_close(outs[0], ref, 2 * BF16_EPS, 6e-3, f"attention(persistent) B{B} N{N} H{H}")
+
+
 @pytest.mark.parametrize("B,N,H", [(1, 577, 2), (2, 300, 1), (1, 1024, 1), (1, 197, 2), (1, 129, 1)])
 def test_attention_online_softmax_chunks(ops, B, N, H):
     g = torch.Generator().manual_seed(N)
