@@ -122,7 +122,10 @@ def generate_features(model, img_3d, mask_3d, flip=None, max_batch=16):
     pending = []
     for s0 in range(0, S, max_batch):
         s1 = min(S, s0 + max_batch)
-        x = prep.prepare_slices(vol[:, :, s0:s1], side=model.cfg.img, flip=flip, device=model.device)
+        # bf16 pixels: the patch GEMM rounds them to bf16 in any case (same round-to-nearest-even, same features bit
+        # for bit); written as bf16 here they are half the bytes, and for p = 16 (MedSAM) the GEMM gathers them straight
+        # from the images (no im2col pass)
+        x = prep.prepare_slices(vol[:, :, s0:s1], side=model.cfg.img, flip=flip, out_dtype=torch.bfloat16, device=model.device)
         if medsam:
             maps = model.engine.forward(x, L.OUT_ENCODER, torch.float32)          # [b, g, g, C] channel-last
         else:
