@@ -815,6 +815,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   {
     VDR_KNOB int pers_env = tuning_env("VDR_GEMM_PERSISTENT", -1);
     if (pers_env >= 0) persistent = persistent && pers_env;
+    if (pers_env == 2 && PIPE >= 50) persistent = true;  // every epilogue (experiments)
     if ((k.abl & 2) && PIPE >= 50) persistent = true;
   }
 #endif
