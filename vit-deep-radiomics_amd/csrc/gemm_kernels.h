@@ -646,10 +646,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4_kernel(Ge
 // that stride.  A workgroup slot is held until its last output store has drained and a fresh workgroup has been
 // launched into it -- stamped (tools/micro/gemm_stamps.hip): the 512 slots are occupied 81-85 % of a launch -- and the
 // loop saves the relaunch.  Measured at M = 50432 (tools/kbench.py in alternating processes, VDR_GEMM_PERSISTENT=0 / 1):
-// fc2 243 -> 235 us, proj 83 -> 82; whole ViT-B forward 10.515 -> 10.445 ms (tools/ab_forward.py).  It is no more than
-// that because the next tile's counted vmcnt waits sit out the drain of the previous tile's stores all the same (vmcnt
-// retires in issue order), and qkv / fc1 LOSE 4-6 % (6-10 VGPRs of their epilogue spill in the loop form): used for the
-// residual epilogue only.  Two things made an earlier attempt lose 13 %: (i) kept live across the loop, the ~75 SGPRs of the
+// fc2 243 -> 235 us, proj 83 -> 82; whole ViT-B forward 10.515 -> 10.445 ms (tools/ab_forward.py).  qkv / fc1 LOSE 4-6 %
+// in this form -- with their output stores removed altogether as well, so it is not the store drain in front of the next
+// tile's loads; the loop's price is the barrier between a tile's epilogue and the next tile's ring fill -- and keep one
+// tile per workgroup: the persistent form is used for the residual epilogue only.  Two things made an earlier attempt lose 13 %: (i) kept live across the loop, the ~75 SGPRs of the
 // argument block and everything loop-invariant derived from them spill (100 SGPRs, 29 VGPRs to scratch) -- the block is
 // re-read per tile through the kernarg pointer made opaque; (ii) hipcc hoists the lane-derived addresses of the body out
 // of the loop (+20 VGPRs at a 128-register budget) -- the body takes an opaque copy of threadIdx.x.
