@@ -431,31 +431,49 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
 // CU, is what that staging waits for).  16-B slot s of row r sits at slot s ^ ((r >> 1) & 7): conflict-free
 // read-back, 2-way on the writes (rows 2k / 2k+1), which an 8-byte write hides.
 // Epilogues that add a residual keep the fp32 staging: the sum has to be rounded once, after the add.
-template <int EPI>
-VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t m_base, int n_base, int lane,
-                           const float2* tile_stats = nullptr) {
-  static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "write-once outputs only");
-  const int r15 = lane & 15, q4 = lane >> 4;
+// The per-column constants (bias, column sums of the folded weight) and per-row statistics of epilogue_bf16, in the
+// accumulator layout.  Fetched by the ring4 body right after its last MFMA is issued -- into the registers the operand
+// fragments have just left -- so that their L2 round trip runs under the drain of the matrix pipe and the barrier that
+// frees the ring instead of at the head of the epilogue.
+struct EpiPre {
   f32x4 bias[4], csum[4];
+  float2 stats[4];
+};
+VDR_DEV EpiPre epilogue_bf16_prefetch(const GemmK& p, int64_t m_base, int n_base, int lane) {
+  EpiPre e;
+  const int r15 = lane & 15, q4 = lane >> 4;
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     int n = n_base + jt * 16 + 4 * q4;
     n = n < p.N ? n : 0;  // out-of-range columns are never stored; keep the address valid
     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    bias[jt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z;
-    csum[jt] = p.ln_fold ? *reinterpret_cast<const f32x4*>(p.colsum + n) : z;
+    e.bias[jt] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z;
+    e.csum[jt] = p.ln_fold ? *reinterpret_cast<const f32x4*>(p.colsum + n) : z;
   }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    float mu = 0.0f, rs = 1.0f;
-    if (tile_stats) {
-      const float2 t = tile_stats[it * 16 + r15];
-      mu = t.x;
-      rs = t.y;
-    } else if (p.ln_stats) {
+    e.stats[it] = float2{0.0f, 1.0f};
+    if (p.ln_stats) {
       int64_t m = m_base + it * 16 + r15;
       m = m < p.M ? m : p.M - 1;
-      const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
+      e.stats[it] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
+    }
+  }
+  return e;
+}
+
+template <int EPI>
+VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t m_base, int n_base, int lane,
+                           const float2* tile_stats, const EpiPre& here) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "write-once outputs only");
+  const int r15 = lane & 15, q4 = lane >> 4;
+  const f32x4 (&bias)[4] = here.bias;
+  const f32x4 (&csum)[4] = here.csum;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    float mu = here.stats[it].x, rs = here.stats[it].y;
+    if (tile_stats) {
+      const float2 t = tile_stats[it * 16 + r15];
       mu = t.x;
       rs = t.y;
     }
@@ -505,7 +523,8 @@ VDR_DEV void epilogue_tile(const GemmK& p, const Acc16& acc, char* smem, int wav
                            const float2* tile_stats = nullptr) {
   if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
     if (!p.out_f32 && p.win_ws == 0 && !p.ln_part) {
-      epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m_base, n_base, lane, tile_stats);
+      epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m_base, n_base, lane, tile_stats,
+                         epilogue_bf16_prefetch(p, m_base, n_base, lane));
       return;
     }
   }

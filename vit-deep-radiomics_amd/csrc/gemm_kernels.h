@@ -612,6 +612,28 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc.t[j][i]));
 #endif
   VDR_GSTAMP(3);  // main loop done (accumulators complete)
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if (!p.out_f32 && p.win_ws == 0 && !p.ln_part && !p.ln_cpart) {
+      // write-once output through the bf16 epilogue: its constants are requested NOW, into the registers the operand
+      // fragments have just left, and used after the barrier (see EpiPre)
+      int lane_here = lane;  // opaque: the loads depend on nothing in the loop, hipcc would hoist them above it
+      asm volatile("" : "+v"(lane_here)::"memory");
+      const EpiPre pre = epilogue_bf16_prefetch(p, m0 + wm * 64, n0 + wn * 64, lane_here);
+      __syncthreads();
+      VDR_GSTAMP(4);
+      epilogue_bf16<EPI>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane, nullptr, pre);
+#ifdef VDR_GEMM_STAMPS
+      asm volatile("" ::: "memory");
+      VDR_GSTAMP(5);
+      st[7] = wall_clock64();
+      if (lane == 0 && p.stamps) {
+        unsigned long long* d = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = st[i];
+      }
+#endif
+      return;
+    }
+  }
   __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
   VDR_GSTAMP(4);
   constexpr int STATS_OFF = NW * 32 * 272;  // behind the wave-private staging images
