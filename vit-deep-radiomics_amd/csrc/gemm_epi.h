@@ -162,7 +162,9 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
       }
     }
   }
-  if (p.bias) {
+  // (with the per-block constants at hand the bias is added unconditionally -- zeros when there is none: as
+  // `p.bias ? v + b : v` hipcc emits the add AND a v_cndmask per value)
+  if (ec.have || p.bias) {
     f32x4 b0 = ec.b0, b1 = ec.b1;
     if (!ec.have) {
       b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -192,7 +194,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     for (int e = 0; e < 8; ++e) v[e] = silu(v[e]) * u[e];
   }
   if (E == EPI_BIAS_RESID) {
-    if (p.gamma) {
+    if (ec.have || p.gamma) {  // (LayerScale: ones when there is none, see the bias above)
       f32x4 g0 = ec.g0, g1 = ec.g1;
       if (!ec.have) {
         g0 = *reinterpret_cast<const f32x4*>(p.gamma + n);

@@ -692,6 +692,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(G
 #pragma unroll
       for (int i = 0; i < NWORDS; ++i) w[i] = src[i];
       __builtin_memcpy(&q, w, sizeof(GemmK));
+      // The copy went through integers, and with it the knowledge that these point to global memory: every access of the
+      // tile became a FLAT instruction (slower, and counted in both vmcnt and lgkmcnt, so each one is waited out).  The
+      // pointers are taken from the argument itself instead -- hipcc promotes those to global -- and only the scalars are
+      // re-read per tile (the pointers a given epilogue uses are a dozen SGPRs, not the 75 of the whole block).
+#define VDR_GLOBAL(f) q.f = p.f
+      VDR_GLOBAL(A);
+      VDR_GLOBAL(W);
+      VDR_GLOBAL(bias);
+      VDR_GLOBAL(resid);
+      VDR_GLOBAL(gamma);
+      VDR_GLOBAL(pos);
+      VDR_GLOBAL(C);
+      VDR_GLOBAL(ln_stats);
+      VDR_GLOBAL(colsum);
+      VDR_GLOBAL(ln_cpart);
+      VDR_GLOBAL(ln_part);
+      VDR_GLOBAL(sA);
+      VDR_GLOBAL(sW);
+      VDR_GLOBAL(sC);
+#undef VDR_GLOBAL
     }
 #else
     const GemmK q = p;
