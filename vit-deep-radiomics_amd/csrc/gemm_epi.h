@@ -139,7 +139,7 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
     if (y >= g || x >= g) return -1;  // zero padding of the border windows: dropped
     orow = (b * g + y) * g + x;
   }
-  if (p.ln_fold) {
+  if (E != EPI_BIAS_RESID && p.ln_fold) {
     // LayerNorm folded into this GEMM: acc = x.W'^T with W' = W.diag(gamma); the row statistics and
     // the column sums of W' turn it into LN(x).W^T; the beta term is already inside p.bias
     f32x4 c0 = ec.c0, c1 = ec.c1;
@@ -316,6 +316,10 @@ VDR_DEV void stage_acc_block(const Acc16& acc, char* stg, int i, int jp, int lan
       *reinterpret_cast<f32x4*>(stg + (it2 * 16 + (lane & 15)) * 272 + (jt * 16 + 4 * (lane >> 4)) * 4) = acc.t[jt][2 * i + it2];
 }
 
+template <int TM, int TN, typename AccT>
+VDR_DEV void epilogue_resid(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane);
+VDR_DEV bool epilogue_resid_ok(const GemmK& p);
+
 template <int EPI, int TM, int TN, typename AccT>
 VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane,
                           const float2* tile_stats = nullptr) {  // tile_stats: LDS (mean, rstd) of row m_base onwards
@@ -324,6 +328,19 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
   (void)MXO;
   constexpr int RS = 272;
   static_assert(TN % 2 == 0, "column tiles are staged in pairs");
+  constexpr bool FOLD = E != EPI_BIAS_RESID;  // (a residual GEMM never consumes a LayerNorm: refused at launch)
+  if constexpr (E == EPI_BIAS_RESID) {
+    // the residual form has its own straight-line epilogue; launches it cannot take (fp32 output, a consumer-side
+    // LayerNorm fold, 2^31 rows) are refused on the host (resid_launch_ok), so the general code below is not even
+    // compiled into the residual kernels -- except for the no-store diagnostic of the tuning builds
+    if (epilogue_resid_ok(p)) {
+      epilogue_resid<TM, TN>(p, acc, stg, m_base, n_base, lane);
+      return;
+    }
+#ifndef VDR_TUNING
+    return;
+#endif
+  }
   // LayerNorm fold: (mean, rstd) of the 4*TM rows this lane owns in the read-back phase, fetched up front
   float st_mu[TM][4], st_rs[TM][4];
 #pragma unroll
@@ -332,11 +349,11 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
     for (int rr = 0; rr < 4; ++rr) {
       st_mu[i][rr] = 0.0f;
       st_rs[i][rr] = 1.0f;
-      if (tile_stats) {
+      if (FOLD && tile_stats) {
         const float2 t = tile_stats[i * 32 + rr * 8 + (lane >> 3)];
         st_mu[i][rr] = t.x;
         st_rs[i][rr] = t.y;
-      } else if (p.ln_stats) {
+      } else if (FOLD && p.ln_stats) {
         int64_t m = m_base + i * 32 + rr * 8 + (lane >> 3);
         m = m < p.M ? m : p.M - 1;
         const float2 t = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
@@ -344,9 +361,6 @@ VDR_DEV void epilogue_lds(const GemmK& p, const AccT& acc, char* stg, int64_t m_
         st_rs[i][rr] = t.y;
       }
     }
-  // (Fetching all of a lane's residual chunks ahead of the first store -- the output usually IS the residual buffer, so
-  // hipcc keeps each residual load behind the stores before it -- was measured: proj -0.6 %, fc2 +1 %, 12 VGPRs spilt.
-  // The loads are not what the residual epilogue waits for.)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -518,6 +532,149 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
     }
   }
 }
+
+// Straight-line residual epilogue: EPI_BIAS_RESID with a bf16 output, x = resid + gamma * (acc + bias), optionally the
+// (sum, sumsq) partials of the rounded outputs for the next LayerNorm and SAM's window un-partition of the rows.  Same
+// arithmetic, same order, same bits as epi_oct through epilogue_lds.
+// Why it exists: in the general path every 8-column group is [residual load -> vmcnt(0) -> arithmetic -> store ->
+// vmcnt(0)] -- the output usually IS the residual buffer, the row / column guards are control flow, and hipcc ends
+// every group by waiting for its stores -- so a lane's 8 groups are 16 memory round trips in a row (stamped: 35 % of a
+// proj tile's life).  Here the residual chunks of a 32 x 64 block are requested ahead of the last store of the block
+// before it, nothing is loaded between a block's first use and its stores, and the guards only predicate the stores.
+// Two build-time shapes of it, measured on ViT-B batch 256 (bench.py in alternating processes, one box; the general
+// epilogue it replaces: 25.40 k img/s, proj 1.127 ms, fc2 2.708 ms per step):
+//   GROUP = 8-row steps computed before their stores are issued together, LATE = the next block's residual is
+//   requested just before this block's last stores (one buffer) instead of while this block is staged (two buffers)
+//   GROUP 1, LATE 1: 25.87 k, proj 0.986, fc2 2.640 (no spills)      <- built
+//   GROUP 2, LATE 1: 25.77 k, proj 0.990, fc2 2.646 (2 VGPRs spilt)
+//   GROUP 1, LATE 0: 25.28 k, proj 1.118, fc2 2.741 (12 spilt: every reload is a vmcnt(0) in front of a store)
+//   GROUP 4, LATE 1: 40 spilt, not run
+#ifndef VDR_RESID_GROUP
+#define VDR_RESID_GROUP 1
+#endif
+#ifndef VDR_RESID_LATE
+#define VDR_RESID_LATE 1
+#endif
+template <int TM, int TN, bool WIN, typename AccT>
+VDR_DEV void epilogue_resid_impl(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane) {
+  constexpr int RS = 272;
+  constexpr int NJ = TN / 2, NB = TM * NJ;  // 32 x 64 blocks of the wave tile
+  constexpr int G = VDR_RESID_GROUP;
+  constexpr bool LATE = VDR_RESID_LATE != 0;
+  constexpr int NR = LATE ? 1 : 2;
+  asm volatile("" : "+v"(lane));  // (opaque: keeps the lane's address terms out of the persistent kernel's tile loop)
+  const int c8 = lane & 7, r8 = lane >> 3;
+  const bool stats = p.ln_part != nullptr;  // wave-uniform
+  const int mrow = (int)m_base + r8, M = (int)p.M;  // rows are < 2^31 (checked at launch): 32-bit row arithmetic
+  // output row of tile row m (-1: not stored)
+  auto out_row = [&](int m) -> int {
+    if (m >= M) return -1;
+    if constexpr (WIN) {  // segment_anything window_unpartition, as in epi_oct
+      const uint32_t ws = p.win_ws, g = p.win_g, nw = (g + ws - 1) / ws, mm = (uint32_t)m;
+      const uint32_t widx = mm / (ws * ws), wtok = mm - widx * (ws * ws);
+      const uint32_t wx = widx % nw, t2 = widx / nw, wy = t2 % nw, b = t2 / nw;
+      const uint32_t y = wy * ws + wtok / ws, x = wx * ws + wtok % ws;
+      if (y >= g || x >= g) return -1;  // zero padding of the border windows: dropped
+      return (int)((b * g + y) * g + x);
+    }
+    return m;
+  };
+  constexpr int NBG = NJ > 1 ? 2 : 1;  // (one column block per wave tile: its bias / gamma are fetched once)
+  int orow[WIN ? 2 : 1][4];            // (identity rows are recomputed where they are used)
+  bf16x8 rsd[NR][4];
+  f32x4 b0[NBG], b1[NBG], g0[NBG], g1[NBG];
+  auto fetch = [&](int blk) {
+    const int i = blk / NJ, jp = blk % NJ, s = blk & 1, sb = NJ > 1 ? s : 0;
+    const int n = n_base + jp * 64 + c8 * 8;
+    const int nn = n < p.N ? n : 0;  // (columns / rows past the end: a valid address, the value is never stored)
+    if (NJ > 1 || blk == 0) {
+      const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f}, one = {1.0f, 1.0f, 1.0f, 1.0f};
+      b0[sb] = b1[sb] = z;
+      g0[sb] = g1[sb] = one;
+      if (p.bias) {
+        b0[sb] = *reinterpret_cast<const f32x4*>(p.bias + nn);
+        b1[sb] = *reinterpret_cast<const f32x4*>(p.bias + nn + 4);
+      }
+      if (p.gamma) {
+        g0[sb] = *reinterpret_cast<const f32x4*>(p.gamma + nn);
+        g1[sb] = *reinterpret_cast<const f32x4*>(p.gamma + nn + 4);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int o = out_row(mrow + i * 32 + rr * 8);
+      if constexpr (WIN) orow[s][rr] = o;
+      rsd[LATE ? 0 : s][rr] = *reinterpret_cast<const bf16x8*>(p.resid + (int64_t)(o < 0 ? 0 : o) * p.ldr + nn);
+    }
+  };
+  fetch(0);
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk) {
+    const int i = blk / NJ, jp = blk % NJ, s = blk & 1, sb = NJ > 1 ? s : 0;
+    const int n = n_base + jp * 64 + c8 * 8;
+    stage_acc_block<TM, TN>(acc, stg, i, jp, lane);
+    if (!LATE && blk + 1 < NB) fetch(blk + 1);  // (this block's accumulators are dead by now; everything up front spills)
+#pragma unroll
+    for (int r0 = 0; r0 < 4; r0 += G) {
+      // G 8-row steps are computed before their stores go out together: with a store per step hipcc reuses the
+      // data registers and each step waits for the store before it
+      bf16x8 o[G];
+      float s1[G], s2[G];
+      int om[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int rr = r0 + k, row = rr * 8 + r8;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 32 + 16);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (t0[e] + b0[sb][e]) * g0[sb][e] + (float)rsd[LATE ? 0 : s][rr][e];
+          v[4 + e] = (t1[e] + b1[sb][e]) * g1[sb][e] + (float)rsd[LATE ? 0 : s][rr][4 + e];
+        }
+        s1[k] = s2[k] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[k][e] = (bf16_t)v[e];
+          const float r = (float)o[k][e];  // statistics of what the consumer will actually read
+          s1[k] += r;
+          s2[k] = fmaf(r, r, s2[k]);
+        }
+        om[k] = WIN ? orow[WIN ? s : 0][rr] : out_row(mrow + i * 32 + rr * 8);
+        if (n >= p.N) om[k] = -1;
+      }
+      // in place (the usual case) hipcc keeps a load behind every store ahead of it: the one-buffer form requests the
+      // next block's residual here, after the last use of this block's and before its last stores
+      if (LATE && r0 + G >= 4 && blk + 1 < NB) fetch(blk + 1);
+#pragma unroll
+      for (int k = 0; k < G; ++k)
+        if (om[k] >= 0) *reinterpret_cast<bf16x8*>(p.C + (int64_t)om[k] * p.ldc + n) = o[k];
+      if (stats) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          float a = om[k] < 0 ? 0.0f : s1[k], b = om[k] < 0 ? 0.0f : s2[k];  // (as epi_oct: a dropped group adds nothing)
+          a += dpp_row_shl<4>(a);
+          b += dpp_row_shl<4>(b);
+          a += dpp_row_shl<2>(a);
+          b += dpp_row_shl<2>(b);
+          a += dpp_row_shl<1>(a);
+          b += dpp_row_shl<1>(b);
+          if (c8 == 0 && om[k] >= 0) {
+            float* dst = p.ln_part + ((int64_t)((n_base + jp * 64) >> 6) * p.part_stride + om[k]) * 2;
+            dst[0] = a;
+            dst[1] = b;
+          }
+        }
+      }
+    }
+  }
+}
+template <int TM, int TN, typename AccT>
+VDR_DEV void epilogue_resid(const GemmK& p, const AccT& acc, char* stg, int64_t m_base, int n_base, int lane) {
+  if (p.win_ws > 0) epilogue_resid_impl<TM, TN, true>(p, acc, stg, m_base, n_base, lane);
+  else epilogue_resid_impl<TM, TN, false>(p, acc, stg, m_base, n_base, lane);
+}
+VDR_DEV bool epilogue_resid_ok(const GemmK& p) { return !VDR_ABL(p, 8); }
 
 // which epilogue a ring3 / ring4 tile takes
 template <int EPI>

@@ -292,7 +292,7 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
 
 hipError_t launch_gemm_mx(const GemmArgs& a, int epilogue, int variant, hipStream_t s) {
   if (a.K <= 0 || (a.K & 63) || (a.N & 63) || a.M <= 0 || !a.a_scale || !a.w_scale) return hipErrorInvalidValue;
-  if (a.ln_stats || a.win_ws || a.a_rpg || a.out_f32) return hipErrorInvalidValue;
+  if (a.ln_stats || a.win_ws || a.a_rpg || a.out_f32 || a.M >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
   if (a.c_scale) {  // MX output
     if (epilogue == EPI_BIAS_GELU) epilogue = EPI_BIAS_GELU_MX;
     else if (epilogue == EPI_SWIGLU) epilogue = EPI_SWIGLU_MX;
