@@ -549,6 +549,11 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
 //   GROUP 2, LATE 1: 25.77 k, proj 0.990, fc2 2.646 (2 VGPRs spilt)
 //   GROUP 1, LATE 0: 25.28 k, proj 1.118, fc2 2.741 (12 spilt: every reload is a vmcnt(0) in front of a store)
 //   GROUP 4, LATE 1: 40 spilt, not run
+// Also measured against GROUP 1 / LATE 1 (another box): each 8-row step requesting the same step of the NEXT block into
+// the registers it has just finished with (a whole block of distance for every chunk), with every store an
+// unconditional buffer store (masked-off lanes carry an out-of-range offset; hipcc's vmcnt then counts exactly instead
+// of assuming the exec-masked stores were skipped): no spills, waits of vmcnt(11) instead of vmcnt(1..3) -- proj 0.997
+// -> 1.009 ms, fc2 2.684 -> 2.686.  With one block of distance the residual is no longer what the steps wait for.
 #ifndef VDR_RESID_GROUP
 #define VDR_RESID_GROUP 1
 #endif
