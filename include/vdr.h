@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 4
+#define VDR_ABI_VERSION 5
 
 typedef enum {
   VDR_OK = 0,
@@ -110,6 +110,11 @@ typedef struct {
   int32_t no_ln_fold; /* 0 (default): pre-LN image models fold norm1 / norm2 into the qkv / fc1 GEMMs (the producers of    */
                       /* the residual stream leave row statistics, gamma goes into the weights: no LayerNorm pass);     */
                       /* 1: keep the explicit LayerNorm kernel (numerics A/B, tests)                                    */
+  int32_t full_last_block; /* 0 (default): with out_mode VDR_OUT_CLS a pre-LN model runs the out-projection, norm2 and */
+                      /* MLP of its LAST block on the CLS rows only -- after the last attention every operation is      */
+                      /* row-wise and x[:, 0] is all `model(x) -> (logits, cls)` (models_archs.py:24-29) returns; the   */
+                      /* features are bitwise those of the full block.  1: every row (A/B, tests, bench.py              */
+                      /* --full-last-block).  Other out_modes, post-LN and fp8 models always run every row.             */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;
@@ -337,7 +342,8 @@ typedef enum {
   VDR_K_GEMM_FC2 = 7,
   VDR_K_FINAL_LN = 8,
   VDR_K_ASSEMBLE = 9,
-  VDR_K_COUNT = 10
+  VDR_K_CLS_TAIL = 10, /* out-projection, norm2 and MLP of the last block on the CLS rows only (vdr_config.full_last_block) */
+  VDR_K_COUNT = 11
 } vdr_kernel_class;
 
 /* When enabled, vdr_forward* brackets every launch with hipEventRecord on the

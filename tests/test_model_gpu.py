@@ -36,12 +36,12 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True, full_last_block=False):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
                        has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
-                       micro_batch=micro_batch, fp8=fp8, ln_fold=ln_fold)
+                       micro_batch=micro_batch, fp8=fp8, ln_fold=ln_fold, full_last_block=full_last_block)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -277,6 +277,29 @@ def test_layernorm_folding_matches_the_explicit_layernorm_path():
     assert r_f <= 1.25 * r_p, "folding LayerNorm must not cost accuracy"
     assert _rel_l2(fused.cpu(), plain.cpu()) <= g
     assert _min_cos(fused.cpu(), ref["tokens"]) >= 0.999
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+@pytest.mark.parametrize("ln_fold", [True, False])
+def test_cls_rows_only_last_block_bitwise(name, ln_fold):
+    """VDR_OUT_CLS runs the out-projection / norm2 / MLP of the LAST block on the CLS rows only (after the last attention
+    every operation is row-wise; models_archs.py:24-29 keeps x[:, 0]).  The features must be the bits of the full block
+    (vdr_config.full_last_block = 1) -- with and without the LayerNorm fold, LayerScale, SwiGLU, micro-batches -- and
+    the full block's own CLS output must equal row 0 of its token output (so the comparison is not vacuous)."""
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=21, scale=0.05)
+    x = vo.make_images(cfg, 7, seed=22).cuda()
+    full = _engine(cfg, w, ln_fold=ln_fold, full_last_block=True)
+    ref_cls = full.forward(x, vdr.OUT_CLS)
+    assert torch.equal(ref_cls, full.forward(x, vdr.OUT_TOKENS)[:, 0])
+    for mb in (0, 3):
+        got = _engine(cfg, w, ln_fold=ln_fold, micro_batch=mb).forward(x, vdr.OUT_CLS)
+        assert torch.equal(got, ref_cls), f"micro_batch {mb}"
+    # the other outputs never take the short cut
+    pruned = _engine(cfg, w, ln_fold=ln_fold)
+    assert torch.equal(pruned.forward(x, vdr.OUT_TOKENS), full.forward(x, vdr.OUT_TOKENS))
+    assert torch.equal(pruned.forward(x, vdr.OUT_DENSE), full.forward(x, vdr.OUT_DENSE))
 
 
 def test_streams_and_micro_batches_do_not_change_results():

@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pass() {  # name, counters...
   name=$1; shift
-  timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$name.log 2>&1
+  timeout -k 10 500 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --full-last-block > gpurun_out/pmc_$name.log 2>&1
   f=$(find gpurun_out/pmc_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp "$f" gpurun_out/pmc_$name.csv
   echo "pass $name: $(wc -l < gpurun_out/pmc_$name.csv) rows"

@@ -10,7 +10,8 @@ NOTE = {"gemm_fc1": "mlp.fc1 + erf-GELU (LayerNorm folded in)", "gemm_fc2": "mlp
         "gemm_qkv": "attn.qkv (LayerNorm folded in)", "gemm_proj": "attn.proj + residual (+ LN partial sums)",
         "attention": "softmax(q k^T / 8) v, 3072 heads of 197 x 64", "gemm_patch": "patchify conv as a GEMM (bf16 images: pixels gathered by the operand loader) + cls/pos",
         "im2col": "image -> patch rows", "layernorm": "ln_finalize: (sum, sumsq) partials -> (mean, rstd)",
-        "final_ln": "final LayerNorm of the CLS rows -> fp32 out", "assemble": "cls row + stats of the token buffer"}
+        "final_ln": "final LayerNorm of the CLS rows -> fp32 out", "assemble": "cls row + stats of the token buffer",
+        "cls_tail": "last block after its attention, CLS rows only: proj + residual, fc1 + GELU, fc2 + residual at M = batch (launch-latency bound)"}
 
 line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
 d = json.loads(line)
@@ -29,6 +30,11 @@ for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"]):
         ach, frac, bound = f"{v.get('TFLOP/s', 0.0):.0f} TFLOP/s", v.get("TFLOP/s", 0.0) / PEAK_TF, "MFMA"
     print(f"| `{k}` | {NOTE.get(k, '')} | {v['launches_per_step']} | {v['ms_per_step']:.3f} | {100 * v['ms_per_step'] / tot:.1f} % | {ach} | {bound} | {frac:.3f} |")
 print(f"| **sum** | | | {tot:.3f} | | {d['TFLOPs_per_s']} TFLOP/s whole forward | MFMA | {d['roofline']['whole_forward_frac']} |")
+if d.get("full_last_block"):
+    f = d["full_last_block"]
+    print(f"\nLast block: {d['config'].get('last_block', '')}.  Every token of the last block computed, as the reference does before it "
+          f"keeps x[:, 0] (same run, same K steps): {f.get('value')} images/s, {f.get('ms_per_step')} ms/step; features bitwise equal: {f.get('features_bitwise_equal')}."
+          f"  FLOPs per image: {d['roofline'].get('flops_per_image_executed', 0) / 1e9:.2f} G executed, {d['roofline'].get('flops_per_image_every_token', 0) / 1e9:.2f} G with every token.")
 if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print(f"\nCPU baseline in the same run: {c['value']} {c['unit']} on {c['cores']} cores ({c['kind']}; {c['sample']}).")

@@ -102,6 +102,7 @@ struct vdr_model {
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
   std::vector<ProfEvent> ev_used, ev_free;
+  int prof_as = -1;  // >= 0: profiler class every launch is booked under (instead of its own)
   double p_flops[VDR_K_COUNT] = {0}, p_bytes[VDR_K_COUNT] = {0};
   int64_t p_launch[VDR_K_COUNT] = {0};
 };
@@ -521,8 +522,9 @@ struct Scope {
   hipStream_t s;
   ProfEvent e;
   bool on;
-  Scope(vdr_model* m_, hipStream_t s_, int cls, double flops, double bytes)
-      : m(m_), s(s_), on(m_->prof && ((m_->prof_mask >> cls) & 1u)) {
+  Scope(vdr_model* m_, hipStream_t s_, int cls, double flops, double bytes) : m(m_), s(s_) {
+    if (m->prof_as >= 0) cls = m->prof_as;  // (block_tail_cls: its small launches are one class of their own)
+    on = m->prof && ((m->prof_mask >> cls) & 1u);
     if (!on) return;
     if (!m->ev_free.empty()) {
       e = m->ev_free.back();
@@ -627,7 +629,8 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
 }
 
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
-         const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold()) {
+         const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold(),
+         int64_t lda = 0, int64_t ldr = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
   GemmArgs g{};
   g.ln_stats = ln.stats;
   g.colsum = ln.colsum;
@@ -647,10 +650,10 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.M = M;
   g.N = N;
   g.K = K;
-  g.lda = K;
+  g.lda = lda ? lda : K;
   g.ldw = K;
   g.ldc = ldc;
-  g.ldr = ldc;
+  g.ldr = ldr ? ldr : ldc;
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
@@ -726,12 +729,59 @@ int gemm_mx(vdr_model* m, hipStream_t s, int cls, const void* aq, const void* as
   return VDR_OK;
 }
 
-int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, const int* lens = nullptr, int len_add = 0) {
+// CLS-only tail of the LAST block (VDR_OUT_CLS: `model(x) -> (logits, cls)`, models_archs.py:24-29 -- the reference
+// computes every token of the last block and then keeps x[:, 0]).  After the last attention nothing mixes rows any
+// more: out-projection, norm2, MLP and the final norm are row-wise, so the [mb] CLS rows are all that reaches the output.
+// They are gathered by the out-projection itself (A and the residual are read with a row stride of ntok * D, the
+// result goes to a compact [mb, D] buffer -- the head of w.h, which no later kernel of this forward reads) and the MLP
+// runs on mb rows instead of mb * ntok.  Same kernels, same per-row arithmetic: the CLS features are bitwise those of
+// the full block (test_cls_rows_only_last_block_bitwise).  vdr_config.full_last_block = 1 keeps every row.
+int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L, int mb, int ntok) {
+  struct BookAs {  // the profiler books these launches as VDR_K_CLS_TAIL, so that gemm_proj / fc1 / fc2 stay classes of
+    vdr_model* m;  // identical full-size launches (their averages are what the rocprofv3 summaries are compared with)
+    explicit BookAs(vdr_model* m_) : m(m_) { m->prof_as = VDR_K_CLS_TAIL; }
+    ~BookAs() { m->prof_as = -1; }
+  } book(m);
+  const vdr_config& c = m->cfg;
+  const int D = c.dim, F = c.mlp_hidden;
+  const bool sw = c.act == VDR_ACT_SWIGLU;
+  const int64_t stride = (int64_t)ntok * D;
+  char* xc = w.h;  // [mb, D] bf16
+  int rc;
+  if (m->ln_fuse) {
+    LnFold prod, cons;
+    prod.part = w.part;
+    prod.part_stride = w.Mp;
+    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, prod, stride, stride)))
+      return rc;
+    if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, mb, sw ? 2 * F : F, D, w, &cons))) return rc;
+    cons.colsum = L.s1;
+    if ((rc = gemm(m, s, VDR_K_GEMM_FC1, xc, L.w1_f, L.t1, nullptr, nullptr, w.u, mb, sw ? 2 * F : F, D, F,
+                   sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
+      return rc;
+  } else {
+    char* hc = w.h + (size_t)round_up(mb, 256) * D * 2;  // norm2 of the compact rows (w.h holds Mp >= mb * ntok + 256 rows)
+    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, LnFold(), stride, stride)))
+      return rc;
+    if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xc, 1, hc, 1, L.n2w, L.n2b, mb, identity_map()))) return rc;
+    if ((rc = gemm(m, s, VDR_K_GEMM_FC1, hc, L.w1, L.b1, nullptr, nullptr, w.u, mb, sw ? 2 * F : F, D, F,
+                   sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+      return rc;
+  }
+  return gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, xc, L.ls2, xc, mb, D, F, D, EPI_BIAS_RESID);
+}
+
+// cls_tail: the caller only wants the CLS rows (see block_tail_cls); *compact is set when they were left in w.h [mb, D]
+int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, const int* lens = nullptr, int len_add = 0,
+               bool cls_tail = false, bool* compact = nullptr) {
   const vdr_config& c = m->cfg;
   const int D = c.dim, F = c.mlp_hidden, H = c.heads;
   const int64_t M = (int64_t)mb * ntok;
   const bool sw = c.act == VDR_ACT_SWIGLU;
   int rc;
+  if (compact) *compact = false;
+  // (the fp8 path keeps every row: its MX activations are laid out in 32-row scale groups; post-LN blocks as well)
+  const int tail_at = (cls_tail && compact && c.pre_ln && !c.fp8 && !c.full_last_block && ntok > 1) ? c.layers - 1 : -1;
   if (c.fp8) {
     // BASELINE config 5: qkv / fc1 / fc2 on the block-scaled fp8 MFMA.  LayerNorm writes its output as MX-fp8
     // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
@@ -783,6 +833,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
       }
+      if (i == tail_at) {
+        *compact = true;
+        return block_tail_cls(m, s, w, L, mb, ntok);
+      }
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
@@ -806,6 +860,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
       VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);
       VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
+    }
+    if (i == tail_at) {
+      *compact = true;
+      return block_tail_cls(m, s, w, L, mb, ntok);
     }
     if (c.pre_ln) {
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
@@ -976,12 +1034,17 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
 }
 
 // slice (and final-normalise) the token buffer into the caller's output
-int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_mode, int out_dtype, char* out) {
+int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_mode, int out_dtype, char* out,
+         bool compact = false) {  // compact: the CLS rows are in w.h [mb, D] (block_tail_cls)
   const vdr_config& c = m->cfg;
   const int D = c.dim;
   RowMap im;
   int64_t rows;
   const int ncls = c.has_cls ? 1 : 0;
+  if (compact) {
+    const int ob = out_dtype == VDR_BF16;
+    return layernorm(m, s, VDR_K_FINAL_LN, w.h, 1, out, ob, m->normw, m->normb, mb, identity_map());
+  }
   if (out_mode == VDR_OUT_CLS) {
     im = RowMap{1, ntok, 0};
     rows = mb;
@@ -1037,8 +1100,8 @@ int vdr_device_count(void) {
 const char* vdr_last_error(vdr_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 const char* vdr_kernel_class_name(int k) {
-  static const char* names[VDR_K_COUNT] = {"im2col",   "gemm_patch", "layernorm", "gemm_qkv", "attention",
-                                           "gemm_proj", "gemm_fc1",  "gemm_fc2",  "final_ln", "assemble"};
+  static const char* names[VDR_K_COUNT] = {"im2col",   "gemm_patch", "layernorm", "gemm_qkv", "attention", "gemm_proj",
+                                           "gemm_fc1", "gemm_fc2",   "final_ln",  "assemble", "cls_tail"};
   return (k >= 0 && k < VDR_K_COUNT) ? names[k] : "?";
 }
 
@@ -1330,10 +1393,11 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.x, 1, m->inw, m->inb, (int64_t)mb * ntok, identity_map())))
         return rc;
     }
-    if ((rc = run_blocks(m, s, w, mb, ntok))) return rc;
+    bool compact = false;
+    if ((rc = run_blocks(m, s, w, mb, ntok, nullptr, 0, out_mode == VDR_OUT_CLS, &compact))) return rc;
     const int64_t rows_per_img = out_mode == VDR_OUT_CLS ? 1 : (out_mode == VDR_OUT_DENSE ? ntok - ncls : ntok);
     char* o = (char*)out + (size_t)b0 * rows_per_img * out_row_bytes(m, out_dtype);
-    if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o))) return rc;
+    if ((rc = emit(m, s, w, mb, ntok, out_mode, out_dtype, o, compact))) return rc;
   }
   if (join_streams(m, caller)) return fail(m, VDR_ERR_HIP, "internal stream join failed");
   return VDR_OK;

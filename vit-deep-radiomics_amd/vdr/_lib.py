@@ -12,7 +12,7 @@ VDR_F32, VDR_BF16, VDR_F64, VDR_I16, VDR_U8 = 0, 1, 2, 3, 4
 ACT_GELU, ACT_SWIGLU = 0, 1
 OUT_CLS, OUT_DENSE, OUT_PATCH_EMBED, OUT_TOKENS, OUT_ENCODER = 0, 1, 2, 3, 4
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_SWIGLU = 0, 1, 2, 3
-K_COUNT = 10
+K_COUNT = 11
 
 
 class VdrError(RuntimeError):
@@ -27,7 +27,8 @@ class vdr_config(C.Structure):
                 ("pre_ln", C.c_int32), ("layerscale", C.c_int32), ("has_cls", C.c_int32), ("has_pos", C.c_int32),
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
                 ("streams", C.c_int32), ("window", C.c_int32),
-                ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32)]
+                ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32),
+                ("full_last_block", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)
@@ -93,7 +94,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vdr_abi_version() != 4:
+    if lib.vdr_abi_version() != 5:
         raise ImportError("libvdr ABI version mismatch")
     _lib = lib
     return lib

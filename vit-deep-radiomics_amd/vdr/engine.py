@@ -35,6 +35,8 @@ class VdrConfig:
     neck_chans: int = 0        # SAM: conv neck output channels (256)
     fp8: int = 0               # 1: qkv / fc1 / fc2 as MX-fp8 (BASELINE config 5)
     ln_fold: bool = True       # pre-LN image models: LayerNorm folded into the qkv / fc1 GEMMs (False: explicit kernel)
+    full_last_block: bool = False  # CLS output: True keeps every row of the last block (default: its CLS rows only,
+                               # the same features bit for bit; see vdr_config.full_last_block)
 
     @property
     def n_patches(self):
@@ -56,6 +58,7 @@ class VdrConfig:
         c.global_mask = sum(1 << int(i) for i in self.global_blocks)
         c.fp8 = int(self.fp8)
         c.no_ln_fold = int(not self.ln_fold)
+        c.full_last_block = int(self.full_last_block)
         return c
 
 

@@ -95,16 +95,17 @@ class VitDescriptorModel:
 
 
 def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0,
-               fp8: int = 0):
+               fp8: int = 0, full_last_block: bool = False):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
     torch.load(weights_only=True).  weights: the same dict passed directly.
     fp8=True keeps the qkv / fc1 / fc2 weights as MX-fp8 and runs them on the block-scaled fp8 MFMA
-    (BASELINE config 5; pre-LN models)."""
+    (BASELINE config 5; pre-LN models).  full_last_block=True: `model(x)` computes every token of the last block
+    like the reference does before it keeps x[:, 0] (default: the CLS rows only, same bits)."""
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
     cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams,
-                       "fp8": int(fp8) or int(ARCHS[model_name].fp8)})
+                       "fp8": int(fp8) or int(ARCHS[model_name].fp8), "full_last_block": bool(full_last_block)})
     if weights is None:
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
