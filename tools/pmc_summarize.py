@@ -39,7 +39,7 @@ def main():
     p2 = load(sys.argv[5]) if len(sys.argv) > 5 else None
     res = {}
     lines = ["# rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ/TCC/GRBM, one pass each; tools/pmc_round.sh) over",
-             "#   python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline      (default config, one MI355X)",
+             "#   python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --full-last-block   (every launch of a class full-size; one MI355X)",
              "# FETCH_SIZE / WRITE_SIZE are KB per dispatch.  On gfx950 FETCH_SIZE reports half of the bytes of wide (16 B/lane)",
              "# coalesced reads (MI355X_MICROARCH.md, HBM): 'read MB' doubles it; WRITE_SIZE is exact for 16-B stores.",
              "# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); values are means per dispatch.",

@@ -423,15 +423,15 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const float* __restrict
   const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (r >= rows) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int g0 = 0; g0 < groups; g0 += 8) {
-    float2 v[8];
+  for (int g0 = 0; g0 < groups; g0 += 16) {
+    float2 v[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {  // 8 independent loads in flight (coalesced across the wave)
+    for (int j = 0; j < 16; ++j) {  // 16 independent loads in flight (coalesced across the wave): one round trip for D <= 1024
       const int g = g0 + j < groups ? g0 + j : groups - 1;
       v[j] = *reinterpret_cast<const float2*>(part + ((int64_t)g * stride + r) * 2);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 16; ++j)
       if (g0 + j < groups) {
         s1 += (double)v[j].x;
         s2 += (double)v[j].y;
