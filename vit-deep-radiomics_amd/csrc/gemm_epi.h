@@ -515,21 +515,49 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
   // read-back: 8 lanes per row, 8 rows per instruction
   const int c8 = lane & 7;
   const int n = n_base + c8 * 8;
+  if (VDR_ABL(p, 8)) {  // diagnostic (tuning builds): everything but the stores
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = rr * 8 + (lane >> 3);
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ ((row >> 1) & 7)) * 16));
+      const int64_t m = m_base + row;
+      if (m < p.M && n < p.N && o[0] == (bf16_t)12345.0f && o[7] == (bf16_t)-54321.0f)
+        *reinterpret_cast<bf16x8*>(p.C + m * p.ldc + n) = o;
+    }
+    return;
+  }
+  // The stores are unconditional buffer stores relative to the wave tile's first row: the resource ends after the
+  // tile's last valid row (rows past M are dropped by the hardware's range check), lanes past N carry an out-of-range
+  // offset, and the 8-row step is a scalar offset -- per step one ds_read_b128 and one buffer_store, no address
+  // arithmetic, no exec-masked branch (as `if (m < M && n < N) *dst = o` a step was ~25 instructions: two 64-bit
+  // multiplies, compare, saveexec, branch, and a wait for its own LDS read that kept the 8 steps in a row).
+  int64_t mb;
+  {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)m_base);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)m_base >> 32));
+    mb = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+  }
+  const int nb = __builtin_amdgcn_readfirstlane(n_base);
+  const int64_t left = p.M - mb;
+  const int valid = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+  const uint32_t ldc2 = (uint32_t)p.ldc * 2u;  // (ldc < 2^24: checked at launch)
+  const __amdgpu_buffer_rsrc_t rc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + mb * p.ldc + nb), 0, (int)((uint32_t)valid * ldc2), 0x00020000);
+  const uint32_t voff = n < p.N ? (uint32_t)(lane >> 3) * ldc2 + (uint32_t)c8 * 16u : 0x7fffffffu;
+  bf16x8 o[8];
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
     const int row = rr * 8 + (lane >> 3);
-    const bf16x8 o = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ ((row >> 1) & 7)) * 16));
-    const int64_t m = m_base + row;
-    if (m < p.M && n < p.N) {
-      bf16x8* dst = reinterpret_cast<bf16x8*>(p.C + m * p.ldc + n);
-      if (VDR_ABL(p, 8)) {
-        if (o[0] == (bf16_t)12345.0f && o[7] == (bf16_t)-54321.0f) *dst = o;
-      } else if (p.nt_store) {
-        __builtin_nontemporal_store(o, dst);
-      } else {
-        *dst = o;
-      }
-    }
+    o[rr] = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((c8 ^ ((row >> 1) & 7)) * 16));
+  }
+  if (p.nt_store) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[rr]), rc, voff, (uint32_t)(rr * 8) * ldc2, 2 /* nt */);
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[rr]), rc, voff, (uint32_t)(rr * 8) * ldc2, 0);
   }
 }
 

@@ -837,6 +837,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.ln_part = a.ln_part;
   k.part_stride = a.part_stride;
   k.ln_fold = a.ln_stats || a.ln_cpart;
+  if (a.ldc >= ((int64_t)1 << 24)) return hipErrorInvalidValue;  // (epilogue_bf16 addresses a wave tile with 32-bit byte offsets)
   // (the residual epilogue, epilogue_resid: bf16 in place or out of place, no consumer-side fold, 32-bit row numbers)
   if (epi == EPI_BIAS_RESID && (k.ln_fold || a.out_f32 || a.M >= ((int64_t)1 << 31))) return hipErrorInvalidValue;
   if (a.ln_cpart) {
