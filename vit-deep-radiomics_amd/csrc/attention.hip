@@ -368,6 +368,21 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
   // compute: one 32-query tile of an item against the staged K / V^T.  Fragment reads run one step
   // ahead of the MFMAs that consume them, and the exp/convert work of key slice i+1 is issued right
   // after the MFMAs of slice i so the VALU and the matrix pipe overlap.
+  // Keys past the sequence (197 tokens: 27 of the last tile's 32) are masked by the MFMA itself: the LAST key tile's
+  // score accumulator starts from this vector (0 for a valid key, -inf past the end) instead of from zero, so the
+  // scores of the padding keys come out as -inf with no instruction spent on them.  As a per-item select on the 16
+  // scores (mask_keys) it was ~85 instructions of every item, 7 % of the loop body.  The sequence length is the same
+  // for every item of a launch, so the vector lives in 16 registers for the whole kernel.
+  // (A launch whose sequence ends before the last tile -- NT is fixed per instantiation, 130 tokens run with NT = 7 --
+  // keeps the select: the vector is all zeros then.)
+  const bool last_tile_only = p.seq > (NT - 1) * 32;  // wave-uniform
+  f32x16 kmask;
+  {
+    const int thr = last_tile_only ? p.seq - (NT - 1) * 32 - 4 * hh : 64;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) kmask[e] = ((e & 3) + 8 * (e >> 2) >= thr) ? -INFINITY : 0.0f;
+    asm volatile("" : "+v"(kmask));  // (opaque: kept, not recomputed per item)
+  }
   auto compute_tile = [&](int item, int next_item, int qt, const char* buf, bf16x8 (&qf)[4]) {
     const int b = item / p.heads;
     const int hd = item - b * p.heads;
@@ -395,8 +410,12 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     kf[0] = *reinterpret_cast<const bf16x8*>(sK + kch[0]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+      if (t == NT - 1) {
+        s[t] = kmask;  // (NT = ceil(seq / 32): only the last tile can hold keys past the end)
+      } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) s[t][e] = 0.0f;
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int i = t * 4 + ks;
@@ -412,9 +431,10 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     VDR_STAMP(2);
     // qf is dead from here: fetch the next item's Q into it; the loads land under the softmax / P.V
     if (next_item >= 0) load_q(next_item, qt, qf);
+    if (!last_tile_only) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (t * 32 + 32 > p.seq) mask_keys(s[t], t * 32, hh, p.seq);
+      for (int t = 0; t < NT; ++t)
+        if (t * 32 + 32 > p.seq) mask_keys(s[t], t * 32, hh, p.seq);
     }
     float mx = -INFINITY;
 #pragma unroll
