@@ -258,7 +258,7 @@ def main():
     # x[:, 0].  The default (timed above) runs the last block's out-projection / MLP on the CLS rows only -- the same
     # features bit for bit -- and that is an algorithmic saving of this path, so both numbers are on the line.
     full = None
-    if not a.full_last_block and not sam and not dense and not a.fp8 and world == 1:
+    if not a.full_last_block and not sam and not dense and world == 1:
         try:
             mf = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
                                 full_last_block=True)
@@ -336,7 +336,7 @@ def main():
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams,
-                          "last_block": "every token" if (a.full_last_block or sam or dense or a.fp8) else
+                          "last_block": "every token" if (a.full_last_block or sam or dense) else
                                         "attention on every token; out-projection / norm2 / MLP on the CLS rows only (bitwise the same features)"},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),

@@ -114,7 +114,7 @@ typedef struct {
                       /* MLP of its LAST block on the CLS rows only -- after the last attention every operation is      */
                       /* row-wise and x[:, 0] is all `model(x) -> (logits, cls)` (models_archs.py:24-29) returns; the   */
                       /* features are bitwise those of the full block.  1: every row (A/B, tests, bench.py              */
-                      /* --full-last-block).  Other out_modes, post-LN and fp8 models always run every row.             */
+                      /* --full-last-block).  Other out_modes and post-LN models always run every row.                  */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

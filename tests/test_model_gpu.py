@@ -279,6 +279,22 @@ def test_layernorm_folding_matches_the_explicit_layernorm_path():
     assert _min_cos(fused.cpu(), ref["tokens"]) >= 0.999
 
 
+@pytest.mark.parametrize("name", ["p16_d128", "p14_d192", "dinov2_swiglu_ls"])
+def test_cls_rows_only_last_block_bitwise_fp8(name):
+    """The same short cut on the MX-fp8 path (BASELINE config 5): norm2 of the CLS rows is quantised on its own, fc1 / fc2
+    run on the block-scaled MFMA at M = batch -- the features must still be the bits of the full block."""
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=23, scale=0.05)
+    x = vo.make_images(cfg, 7, seed=24).cuda()
+    full = _engine(cfg, w, fp8=1, full_last_block=True)
+    ref_cls = full.forward(x, vdr.OUT_CLS)
+    assert torch.equal(ref_cls, full.forward(x, vdr.OUT_TOKENS)[:, 0])
+    for mb in (0, 3):
+        assert torch.equal(_engine(cfg, w, fp8=1, micro_batch=mb).forward(x, vdr.OUT_CLS), ref_cls), f"micro_batch {mb}"
+    assert torch.equal(_engine(cfg, w, fp8=1).forward(x, vdr.OUT_DENSE), full.forward(x, vdr.OUT_DENSE))
+
+
 @pytest.mark.parametrize("name", sorted(SMALL))
 @pytest.mark.parametrize("ln_fold", [True, False])
 def test_cls_rows_only_last_block_bitwise(name, ln_fold):

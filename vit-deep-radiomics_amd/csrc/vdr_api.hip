@@ -748,6 +748,22 @@ int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L,
   const int64_t stride = (int64_t)ntok * D;
   char* xc = w.h;  // [mb, D] bf16
   int rc;
+  if (c.fp8) {
+    // MX-fp8 linears: norm2 of the compact rows goes out as MX-fp8 behind them in w.h (payload) / w.hs (scales: the
+    // layouts depend only on the row count each launch is given), fc1 / fc2 on the block-scaled MFMA at M = mb
+    char* hq = w.h + (size_t)round_up(mb, 256) * D * 2;
+    const int N1 = sw ? 2 * F : F;
+    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, LnFold(), stride, stride)))
+      return rc;
+    {
+      Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)mb * D * 3);
+      VDR_TRY(launch_ln_mx(xc, L.n2w, L.n2b, c.ln_eps, mb, D, hq, w.hs, s), "layernorm_mx");
+    }
+    if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC1, hq, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, mb, N1, D, F,
+                      sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+      return rc;
+    return gemm_mx(m, s, VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, xc, L.ls2, xc, nullptr, mb, D, F, D, EPI_BIAS_RESID);
+  }
   if (m->ln_fuse) {
     LnFold prod, cons;
     prod.part = w.part;
@@ -780,8 +796,9 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
   const bool sw = c.act == VDR_ACT_SWIGLU;
   int rc;
   if (compact) *compact = false;
-  // (the fp8 path keeps every row: its MX activations are laid out in 32-row scale groups; post-LN blocks as well)
-  const int tail_at = (cls_tail && compact && c.pre_ln && !c.fp8 && !c.full_last_block && ntok > 1) ? c.layers - 1 : -1;
+  // (post-LN blocks keep every row: their last operation is a LayerNorm over the block's own output, also row-wise, but
+  // the classifier that uses them is not a throughput path)
+  const int tail_at = (cls_tail && compact && c.pre_ln && !c.full_last_block && ntok > 1) ? c.layers - 1 : -1;
   if (c.fp8) {
     // BASELINE config 5: qkv / fc1 / fc2 on the block-scaled fp8 MFMA.  LayerNorm writes its output as MX-fp8
     // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
@@ -800,6 +817,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
         VDR_KNOB int attn_variant = env_int("VDR_ATTN_VARIANT", 0);  // (tuning builds)
         VDR_TRY(launch_attention(w.qkv, w.o, mb, ntok, H, attn_variant, s, nullptr, lens, len_add), "attention");
+      }
+      if (i == tail_at) {
+        *compact = true;
+        return block_tail_cls(m, s, w, L, mb, ntok);
       }
       // the out-projection stays bf16: quantising it too measured 0.987 row cosine at 40 blocks (gate 0.99)
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
