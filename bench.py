@@ -15,6 +15,12 @@ One "step" = one pass of the hot path over one batch of synthetic images already
 BASELINE config 3 = 8 x 256) and ONE all-gather (RCCL over xGMI) reassembles the [N*256,768]
 feature matrix inside the step.  Rank 0 prints ONE JSON line.
 
+Last block: with a CLS output the library runs the last block's out-projection / norm2 / MLP on the CLS rows only (after
+the last attention every operation is row-wise and x[:, 0] is all `model(x) -> (logits, cls)` returns; the features are
+the bits of the full computation, checked in every run: full_last_block.features_bitwise_equal).  `value` is that
+default; `full_last_block.value` (same run, same K steps) computes every token like the reference; the FLOP counts of
+both are on the line and whole_forward_frac prices the FLOPs actually executed.  --full-last-block times the latter.
+
 roofline: the dominant kernel class (by summed time) of the timed region, timed with HIP events
 recorded by libvdr on the stream the kernels are launched on (vdr_profile_*): achieved = algorithmic
 FLOPs of those launches / their summed duration; peak = 2.5 PFLOP/s dense bf16 MFMA.
