@@ -582,6 +582,9 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
 // unconditional buffer store (masked-off lanes carry an out-of-range offset; hipcc's vmcnt then counts exactly instead
 // of assuming the exec-masked stores were skipped): no spills, waits of vmcnt(11) instead of vmcnt(1..3) -- proj 0.997
 // -> 1.009 ms, fc2 2.684 -> 2.686.  With one block of distance the residual is no longer what the steps wait for.
+// And: the first block's residual / bias / LayerScale requested by ring4 before the barrier that ends its main loop (as
+// EpiPre does for the write-once outputs): proj 0.892 -> 0.914 ms, fc2 2.296 -> 2.338 (3 VGPRs spilt in the persistent
+// kernel at its 128-register budget) -- not kept.
 #ifndef VDR_RESID_GROUP
 #define VDR_RESID_GROUP 1
 #endif
