@@ -21,7 +21,7 @@ acc = collections.defaultdict(list)
 for f in sorted(glob.glob("gpurun_out/ab/*_?.json")):
     d = json.loads(open(f).read().strip().splitlines()[-1])
     k = d["kernels"]
-    acc[f.split("/")[-1].rsplit("_", 1)[0]].append((d["value"], k["gemm_proj"]["ms_per_step"], k["gemm_fc2"]["ms_per_step"], k["gemm_qkv"]["ms_per_step"], k["gemm_fc1"]["ms_per_step"]))
+    acc[f.split("/")[-1].rsplit("_", 1)[0]].append((d["value"], k["gemm_proj"]["ms_per_step"], k["gemm_fc2"]["ms_per_step"], k["gemm_qkv"]["ms_per_step"], k["gemm_fc1"]["ms_per_step"], k["layernorm"]["ms_per_step"]))
 for n, v in acc.items():
-    print(n, "img/s", [round(x[0]) for x in v], "proj", [x[1] for x in v], "fc2", [x[2] for x in v], "qkv", [x[3] for x in v], "fc1", [x[4] for x in v])
+    print(n, "img/s", [round(x[0]) for x in v], "proj", [x[1] for x in v], "fc2", [x[2] for x in v], "qkv", [x[3] for x in v], "fc1", [x[4] for x in v], "ln", [x[5] for x in v])
 PY
