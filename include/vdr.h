@@ -302,8 +302,7 @@ int vdr_op_voxel_sequence(const float* feat, const int64_t* index, const double*
  *   qkv [batch*seq, 3*H*64] bf16, row = token, columns [q | k | v] each [H, 64]
  *   out [batch*seq, H*64] bf16;  softmax(q k^T / 8) v per (batch, head), no mask.
  *   variant: 0 = library choice; 1 = chunked (online softmax over 128-key chunks), 2 = persistent kernel without,
- *   4 = with its loader wave (sequences of 129..224 tokens), 5 = that kernel software-pipelined across items
- *   (193..224 tokens; other lengths: the library choice), 3 = one workgroup per (batch, head).  All variants
+ *   4 = with its loader wave (sequences of 129..224 tokens), 3 = one workgroup per (batch, head).  All variants
  *   produce the same bits for sequences that fit one chunk. */
 int vdr_op_attention(const void* qkv, void* out, int batch, int seq, int heads, int variant,
                      void* stream);

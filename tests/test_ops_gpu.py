@@ -285,21 +285,6 @@ def test_attention_persistent_kernels_match_one_shot_bitwise(ops, B, N, H):
     _assert_close(outs[0], ref, 2 * BF16_EPS, 6e-3, f"attention(persistent) B{B} N{N} H{H}")
 
 
-@pytest.mark.parametrize("B,N,H", [(43, 197, 12), (256, 197, 12), (3, 224, 2), (1, 193, 7), (5, 208, 1), (700, 209, 1), (2, 197, 1)])
-def test_attention_pipelined_kernel_matches_one_shot_bitwise(ops, B, N, H):
-    """Variant 5: the persistent kernel software-pipelined across items (K.Q^T of the next item inside the softmax / P.V
-    phase of the current one; 193..224 tokens).  Same arithmetic per element: bitwise equal to the one-shot kernel --
-    with one item per workgroup, with many (700 items on 256 CUs: 3 per workgroup, the last round partial), with the
-    last key tile full (224), holding one key (193) and with a fully masked 14th slice (193..208)."""
-    g = torch.Generator().manual_seed(B * 17 + N)
-    qkv = _bf(torch.randn(B * N, 3 * H * 64, generator=g))
-    a = ops.attention(qkv.cuda(), B, N, H, variant=3)
-    b = ops.attention(qkv.cuda(), B, N, H, variant=5)
-    assert torch.equal(a, b), f"pipelined B{B} N{N} H{H}"
-    for _ in range(2):  # (stale LDS / registers from the previous launch must not matter)
-        assert torch.equal(ops.attention(qkv.cuda(), B, N, H, variant=5), a)
-
-
 @pytest.mark.parametrize("B,N,H", [(1, 577, 2), (2, 300, 1), (1, 1024, 1), (1, 197, 2), (1, 129, 1)])
 def test_attention_online_softmax_chunks(ops, B, N, H):
     g = torch.Generator().manual_seed(N)

@@ -11,6 +11,8 @@
 //   4  8 waves, all V
 //   5  4 waves, all X           (one wave per SIMD doing both)
 //   6  8 waves, all X
+//   7  as 2, the V waves at s_setprio 3      8  as 2, the M waves at s_setprio 3
+//   9  as 6, waves 4-7 at s_setprio 3
 // Prints the kernel time and, per SIMD, cycles per round (shader clock from s_memtime around the loop of wave 0).
 //   hipcc --offload-arch=gfx950 -O3 -o coissue coissue.hip && ./coissue <mode> <shape 0|1> <vpm>
 #include <hip/hip_runtime.h>
@@ -64,8 +66,9 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* sink, unsig
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
-  const bool is_v = mode == 1 || mode == 4 || (mode == 2 && wave >= 4);
-  const bool is_x = mode >= 5;
+  const bool is_v = mode == 1 || mode == 4 || ((mode == 2 || mode == 7 || mode == 8) && wave >= 4);
+  const bool is_x = mode == 5 || mode == 6 || mode == 9;
+  if ((mode == 7 && wave >= 4) || (mode == 8 && wave < 4) || (mode == 9 && wave >= 4)) __builtin_amdgcn_s_setprio(3);
   if (is_x) body<SHAPE, VPM, true, true>(iters, sink, lane);
   else if (is_v) body<SHAPE, VPM, false, true>(iters, sink, lane);
   else body<SHAPE, VPM, true, false>(iters, sink, lane);
@@ -104,7 +107,7 @@ int run(int mode, int iters) {
 int main(int argc, char** argv) {
   const int iters = 20000;
   for (int shape = 0; shape < 2; ++shape)
-    for (int mode = 0; mode <= 6; ++mode) {
+    for (int mode = 0; mode <= 9; ++mode) {
       int rc = 0;
       if (shape == 0) {
         rc |= run<0, 32>(mode, iters);

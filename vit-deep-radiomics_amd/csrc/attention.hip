@@ -320,6 +320,7 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
       // the loader wave: all NT*8 pieces, a rolled loop with the lane part of the address rebuilt per piece (kept
       // unrolled, hipcc hoists 56 64-bit addresses out of the item loop and spills)
       if (wave != NCW) return;
+      __builtin_amdgcn_s_setprio(3);  // (the loader's 56 DMA instructions go ahead of the computing waves' work)
       const uint32_t ldb = (uint32_t)p.ld_qkv * 2;
       const int r0 = lane >> 3;
       const uint32_t ck = (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);               // K chunk, ^ 64 on odd pieces
@@ -407,6 +408,12 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     // intended ISA, 215 VGPRs) measured the same within the A/B harness's noise (tools/ab_libs.py: 81.2 vs 79.3 us):
     // with two waves per SIMD the partner's instructions already fill those waits, so the plain form stays.
     bf16x8 kf[2];
+    // Wave priority follows the phase: low while this wave streams the 28 MFMAs of K.Q^T, high for the softmax / P.V
+    // phase that is mostly vector work.  A wave that has an MFMA ready whenever the pipe frees up otherwise holds the
+    // SIMD's issue slot and the other wave's vector instructions wait behind it (tools/micro/coissue.hip, modes 2 / 7:
+    // a vector wave next to an MFMA wave runs at 440 cycles per round without and 224 with the higher priority, the MFMA
+    // wave at its full 256 either way).
+    __builtin_amdgcn_s_setprio(0);
     kf[0] = *reinterpret_cast<const bf16x8*>(sK + kch[0]);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -429,6 +436,7 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(s[t]));
 #endif
     VDR_STAMP(2);
+    __builtin_amdgcn_s_setprio(2);
     // qf is dead from here: fetch the next item's Q into it; the loads land under the softmax / P.V
     if (next_item >= 0) load_q(next_item, qt, qf);
     if (!last_tile_only) {
@@ -564,310 +572,6 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
   }
 }
 
-// Software-pipelined form of the persistent kernel: S(i+1) = K(i+1).Q(i+1)^T is computed INSIDE item i's softmax / P.V
-// phase, tile by tile into the score registers item i has just finished with.
-// Why: on this chip matrix and vector work overlap only inside a wave (tools/micro/coissue.hip,
-// profiles/r02_coissue_micro.txt: one wave issuing 8 MFMAs and 32 fmas interleaved takes 276 cycles where the MFMAs alone
-// take 256; the same work in two waves of a SIMD takes 256 + 176 -- a wave that has an MFMA ready whenever the pipe
-// frees up holds the SIMD's issue slot).  In attn_persist_kernel the 28 MFMAs of K.Q^T run back to back with nothing
-// to issue between them (~900 cycles of every item in which neither this wave nor its SIMD partner does vector work);
-// here each key tile's 4 MFMAs go out between the exponentials of the slices that follow, and the row maximum of the
-// next item is collected one tile behind them.
-// Data flow per item i (buffers alternate with the parity of i): V(i) and K(i+1) are in LDS at the item barrier; the
-// loader wave then fetches K(i+2) into the image K(i) has left and V(i+1) into the one V(i-1) has left; Q(i+1) is in
-// registers, Q(i+2) is requested at the top of the item and takes Q(i+1)'s place after the last K.Q^T MFMA.
-// Same arithmetic in the same order per element as attn_persist_kernel: bit-identical output.
-// Launched for sequences whose padding lies in the last key tile only ((NT-1)*32 < seq <= NT*32: the kmask form).
-template <int NT>
-__global__ __launch_bounds__(512, 2) void attn_pipe_kernel(AttnK p, int n_items) {
-  constexpr int KEYS = NT * 32;
-  constexpr int IMG = KEYS * 128;  // one K or V image: [key][64 d] rows of 128 B
-  constexpr int NCW = 7;           // computing waves == query tiles per item; wave 7 is the loader
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | V0 | K1 | V1]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hh = lane >> 5;
-  const int l31 = lane & 31;
-  const int swz = (lane >> 1) & 7;
-  const int HD = p.heads * 64;
-  const int nqt = (p.seq + 31) >> 5;
-  const float sc = 0.125f * 1.44269504088896341f;
-
-  // loader wave: one image (K or V rows of `item`), same chunk swizzles as attn_persist_kernel
-  auto issue = [&](int item, bool isv, char* img) {
-    const int b = item / p.heads;
-    const int hd = item - b * p.heads;
-    const bf16_t* src = p.qkv + (int64_t)b * p.seq * p.ld_qkv + hd * 64 + HD + (isv ? HD : 0);
-    const uint32_t ldb = (uint32_t)p.ld_qkv * 2;
-    const int r0 = lane >> 3;
-    const uint32_t ck = (uint32_t)(((lane & 7) ^ (lane >> 4)) * 16);               // K chunk, ^ 64 on odd pieces
-    const uint32_t cv = (uint32_t)(((lane & 7) ^ (((lane >> 4) & 1) << 2)) * 16);  // V chunk
-#pragma unroll 2
-    for (int i = 0; i < NT * 4; ++i) {
-      const int r = i * 8 + r0;
-      const uint32_t row = (uint32_t)(r < p.seq ? r : p.seq - 1) * ldb;
-      glds16_raw(src, row + (isv ? cv : (ck ^ (uint32_t)((i & 1) << 6))), img + i * 1024);
-    }
-  };
-  auto load_q = [&](int item, bf16x8 (&q)[4]) {
-    const int b = item / p.heads;
-    const int hd = item - b * p.heads;
-    int qr = wave * 32 + l31;
-    qr = qr < p.seq ? qr : p.seq - 1;
-    const bf16_t* src = p.qkv + ((int64_t)b * p.seq + qr) * p.ld_qkv + hd * 64 + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(src + ks * 16);
-  };
-
-  // the 0 / -inf start vector of the last key tile (see attn_persist_kernel) lives in LDS behind the four images, one
-  // copy per wave: this kernel has no 16 registers to keep it in
-  f32x16* const kmask_lds = reinterpret_cast<f32x16*>(smem + 4 * IMG + wave * 4096) + lane;
-  {
-    const int thr = p.seq - (NT - 1) * 32 - 4 * hh;
-    f32x16 km;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) km[e] = ((e & 3) + 8 * (e >> 2) >= thr) ? -INFINITY : 0.0f;
-    *kmask_lds = km;  // (read back by the same lane only)
-  }
-  int kch[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) kch[ks] = ((2 * ks + hh) ^ swz) * 16;
-  // one key tile of S^T = K.Q^T into st (which may still hold the previous item's scores of that tile: dead by now)
-  auto qk_tile = [&](int t, const char* kimg, const bf16x8 (&q)[4]) -> f32x16 {
-    const char* sK = kimg + l31 * 128 + t * 32 * 128;
-    f32x16 st;
-    if (t == NT - 1) {
-      st = *kmask_lds;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[e] = 0.0f;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kch[ks]);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q[ks], st, 0, 0, 0);
-    }
-    return st;
-  };
-  auto tile_max = [&](const f32x16 st, float mx) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[e]);
-    return mx;
-  };
-
-  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  const int tq = (lane & 15) >> 2, tp = lane & 3, dg = (lane >> 4) & 1;
-  const int vkey = 4 * hh + tq;
-  int vch[2];
-#pragma unroll
-  for (int nd = 0; nd < 2; ++nd) vch[nd] = ((4 * nd + 2 * dg + (tp >> 1)) ^ (((vkey >> 1) & 1) << 2)) * 16;
-
-  int item = blockIdx.x;
-  if (item >= n_items) return;
-  const int stride = __builtin_amdgcn_readfirstlane(gridDim.x);
-  const bool computes = wave < nqt;  // nqt <= NCW (checked by the launcher)
-  const bool loader = wave == NCW;
-  auto kimg = [&](int j) { return smem + j * (2 * IMG); };        // j = 0 / 1
-  auto vimg = [&](int j) { return smem + j * (2 * IMG) + IMG; };
-
-  f32x16 s[NT];
-  bf16x8 qf[4], qn[4];
-  float mx = -INFINITY;
-  // ---- prologue: K(0), V(0), K(1) staged; S(0) and its row maximum; Q(1) in registers ----
-  if (loader) {
-    issue(item, false, kimg(0));
-    issue(item, true, vimg(0));
-    if (item + stride < n_items) issue(item + stride, false, kimg(1));
-  }
-  if (computes) {
-    load_q(item, qn);
-    if (item + stride < n_items) load_q(item + stride, qf);
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qn[ks]), "+v"(qf[ks]));
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (computes) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) s[t] = qk_tile(t, kimg(0), qn);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) mx = tile_max(s[t], mx);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  }
-
-  // every wave passes exactly one barrier per item; the three roles run their own loops (one loop with role branches
-  // makes the 112 loop-carried score registers phis of the other roles' paths)
-  if (!computes) {
-    int par = 0;
-    for (; item < n_items; item += stride, par ^= 1) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (loader) {
-        const int next = item + stride, next2 = next + stride;
-        if (next2 < n_items) issue(next2, false, kimg(par));
-        if (next < n_items) issue(next, true, vimg(par ^ 1));
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-    }
-    return;
-  }
-  int par = 0;
-  for (; item < n_items; item += stride, par ^= 1) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // V(i) and K(i+1) have landed; nobody reads K(i) or V(i-1) any more
-    asm volatile("" ::: "memory");
-    const int next = item + stride, next2 = next + stride;
-    const bool has_next2 = next2 < n_items;
-    // Q(i+2) lands during the item and becomes qf after the last K.Q^T MFMA below.  (Past the end of the list the
-    // pipeline keeps running on whatever is at hand -- this item's Q again, the K image of two items ago -- and its
-    // results are never used: as branches around the K.Q^T tiles they would make every score tile a phi of two
-    // register tuples, and hipcc then copies all 112 score registers at the loop edge and spills 350.)
-    load_q(has_next2 ? next2 : item, qn);
-    const int b = item / p.heads;
-    const int hd = item - b * p.heads;
-    // (opaque per item: with 112 score registers carried around the loop there is no room for the LDS addresses of
-    // both parities that hipcc would otherwise compute once and keep)
-    int par_v = par;
-    asm volatile("" : "+v"(par_v));
-    const char* kn = smem + (par_v ^ 1) * (2 * IMG);
-    const __attribute__((address_space(3))) char* sV =
-        (const __attribute__((address_space(3))) char*)(smem + par_v * (2 * IMG) + IMG) + vkey * 128 + 8 * (tp & 1);
-    const float mb = mx * sc;
-    float mxn = -INFINITY;
-    float lsum = 0.0f;
-    f32x16 o[2];
-#pragma unroll
-    for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
-    constexpr int NI = NT * 2;  // 16-key slices
-    bf16x4 vlo[2], vhi[2];
-    bf16x8 pf[2];
-    auto read_v = [&](int it) {
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd) {
-        vlo[nd] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + vch[nd]));
-        vhi[nd] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + 8 * 128 + vch[nd]));
-      }
-    };
-    auto make_p = [&](int it, int set) {
-      const int t = it >> 1, s2 = it & 1;
-#ifdef VDR_TUNING
-      if (p.abl & 4) {  // diagnostic: no exponentials / sums / conversions
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[set][j] = (bf16_t)1.0f;
-        return;
-      }
-#endif
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
-        lsum += pv;
-        pf[set][j] = (bf16_t)pv;
-      }
-    };
-    // K fragments of the next item's key tile, read a whole slice pair before the MFMAs that consume them (read right
-    // in front of their MFMA each of the 28 LDS round trips of an item is waited out: the score tiles' 4 MFMAs are a
-    // dependent chain with nothing else of this wave to issue in between)
-    bf16x8 kfr[4];
-    auto read_k = [&](int t) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kfr[ks] = *reinterpret_cast<const bf16x8*>(kn + l31 * 128 + t * 32 * 128 + kch[ks]);
-    };
-    read_k(0);
-    read_v(0);
-    make_p(0, 0);
-    // (a static loop: as `#pragma unroll` with the validity test as a break hipcc refuses to unroll this body, and the
-    // score tiles, indexed by the slice number, would live in scratch)
-    static_for<0, NI>([&](auto IT) {
-      constexpr int it = decltype(IT)::value;
-      constexpr int cur = it & 1;
-      // (a fully masked slice -- the 14th of 14 at 197 tokens -- is computed like the others: P = exp2(-inf) = 0
-      // exactly and the V rows past the end are copies of the last valid one, so it adds nothing; skipping it under a
-      // wave-uniform test makes the output accumulators phis of two tuples, see above)
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd) {
-        bf16x8 vf;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vf[j] = vlo[nd][j];
-          vf[4 + j] = vhi[nd][j];
-        }
-#ifdef VDR_TUNING
-        if (p.abl & 16) {  // diagnostic: no P.V MFMAs (operands stay live)
-          asm volatile("" ::"v"(vf), "v"(pf[cur]));
-          continue;
-        }
-#endif
-        o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[cur], o[nd], 0, 0, 0);
-      }
-      if (it + 1 < NI) {
-        read_v(it + 1);
-        make_p(it + 1, cur ^ 1);
-      }
-      if (it & 1) {
-        // both slices of key tile t have been turned into P: its score registers take S(i+1)'s tile t, and the row
-        // maximum of the tile before it (whose MFMAs have had a slice's worth of time to finish) is folded in
-        constexpr int t = it >> 1;
-        {
-          f32x16 st;
-          if (t == NT - 1) {
-            st = *kmask_lds;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) st[e] = 0.0f;
-          }
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
-          s[t] = st;
-        }
-        if (t + 1 < NT) read_k(t + 1);
-        if (t > 0) mxn = tile_max(s[t > 0 ? t - 1 : 0], mxn);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    const float l = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / l;
-    const int q = wave * 32 + l31;
-    mxn = tile_max(s[NT - 1], mxn);
-    mx = fmaxf(mxn, __shfl_xor(mxn, 32, 64));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // Q(i+2) (requested at the top of the item)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      asm volatile("" : "+v"(qn[ks]));
-      qf[ks] = qn[ks];
-    }
-    attn_store_row(p, o, inv, q < p.seq, (int64_t)b * p.seq + (q < p.seq ? q : 0), hd, hh);
-  }
-}
-
-template <int NT>
-static hipError_t launch_pipe(const AttnK& k, int batch, hipStream_t s) {
-  constexpr size_t lds = 4 * (size_t)(NT * 32 * 128) + 8 * 4096;  // four images + the per-wave mask vectors
-  auto fn = attn_pipe_kernel<NT>;
-  static bool attr_set = false;  // per instantiation: raised once, not per launch
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  const int n_items = batch * k.heads;
-  const int grid = n_items < n_cu ? n_items : n_cu;
-  hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), lds, s, k, n_items);
-  return hipGetLastError();
-}
-
 template <int NT, bool LOADER>
 static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(2 * NT * 32 * 128);
@@ -917,9 +621,8 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   variant %= 10;
 #else
   k.abl = 0;
-  // 0 library choice, 1 chunked (online softmax), 2 persistent without the loader wave, 3 one-shot, 4 persistent with it,
-  // 5 persistent, software-pipelined across items (193..224 tokens; other lengths fall through to the library choice)
-  if (variant < 0 || variant > 5) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
+  // 0 library choice, 1 chunked (online softmax), 2 persistent without the loader wave, 3 one-shot, 4 persistent with it
+  if (variant < 0 || variant > 4) return hipErrorInvalidValue;  // (ablation encodings exist in tuning builds only)
 #endif
   k.qkv = (const bf16_t*)qkv;
   k.out = (bf16_t*)out;
@@ -940,10 +643,6 @@ hipError_t launch_attention(const void* qkv, void* out, int batch, int seq, int 
   }
   k.qt_per_block = nqt;
   k.n_chunks = 1;
-  if (variant == 5) {
-    if (!lens && seq > 192 && seq <= 224) return launch_pipe<7>(k, batch, s);
-    variant = 0;
-  }
   if ((variant == 2 || variant == 4 || variant == 0) && !lens) {  // (per-sequence lengths: one-shot kernel only)
     // persistent warp-specialised kernel (needs a few items per workgroup to pay off)
     if (variant == 4 && seq > 128 && seq <= 224) return launch_persist<7, true>(k, batch, s);

@@ -1,8 +1,6 @@
 // Device-side helpers shared by the gfx950 kernels (wave = 64 lanes, CDNA4 MFMA).
 #pragma once
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
@@ -72,17 +70,6 @@ VDR_DEV float gelu_erf(float x) {
 }
 
 VDR_DEV float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-x * 1.44269504088896341f)); }
-
-// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (a body hipcc will not unroll by pragma, or one
-// whose register arrays must be indexed by constants)
-template <int B, int E, typename F>
-VDR_DEV void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-
 // Key mask of one 32-key tile of the attention kernels: accumulator element e of lane (.., hh) is key
 // k0 + (e & 3) + 8 (e >> 2) + 4 hh; keys >= len get -inf.  Written as (constant >= per-lane threshold) with the threshold
 // made opaque on every call: comparing `key >= len` directly let hipcc hoist all 16 x NT lane masks out of the item loop
