@@ -76,6 +76,24 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, float* sink, unsig
   if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
 
+// transcendental rate: `iters` rounds of 32 independent v_exp_f32 (8 chains), 4 or 8 waves per workgroup
+__global__ __launch_bounds__(512) void kexp(int iters, float* sink, unsigned long long* cyc) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float v[8];
+  for (int j = 0; j < 8; ++j) v[j] = -0.001f * (lane + j);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 32; ++j) asm volatile("v_exp_f32 %0, %0" : "+v"(v[j & 7]));
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.0f;
+  for (int j = 0; j < 8; ++j) s += v[j];
+  if (s == 123456.789f) sink[lane] = s;
+  if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
+
 template <int SHAPE, int VPM>
 int run(int mode, int iters) {
   float* sink;
@@ -106,6 +124,21 @@ int run(int mode, int iters) {
 
 int main(int argc, char** argv) {
   const int iters = 20000;
+  for (int waves = 4; waves <= 8; waves += 4) {
+    float* sink;
+    unsigned long long* cyc;
+    CK(hipMalloc(&sink, 4096));
+    CK(hipMalloc(&cyc, 64));
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(kexp, dim3(256), dim3(waves * 64), 0, 0, iters, sink, cyc);
+      CK(hipDeviceSynchronize());
+    }
+    unsigned long long h[8];
+    CK(hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost));
+    printf("v_exp_f32 x32 per round, %d waves: ticks per round", waves);
+    for (int w = 0; w < waves; ++w) printf(" %.1f", (double)h[w] / iters);
+    printf("\n");
+  }
   for (int shape = 0; shape < 2; ++shape)
     for (int mode = 0; mode <= 9; ++mode) {
       int rc = 0;
