@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
 
   auto process = [&](int kc0, bool rescale) {
     f32x16 s[NT];
+    __builtin_amdgcn_s_setprio(0);  // (low for the K.Q^T MFMAs, high for the vector-heavy rest: see attn_persist_kernel)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(2);
     // mask keys >= seq (only tiles that straddle or lie beyond the end)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

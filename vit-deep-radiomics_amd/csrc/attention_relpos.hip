@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     const char* sK = buf;
     const __attribute__((address_space(3))) char* sVtr = (const __attribute__((address_space(3))) char*)buf + vbase;
     f32x16 s[NT];
+    __builtin_amdgcn_s_setprio(0);  // (low for the K.Q^T MFMAs, high for the vector-heavy rest: attention.hip, attn_persist_kernel)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       // MULTI: the first MFMA takes 8 rel_w[kw] as its C operand (registers that never change: no per-element add, no
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], (MULTI && ks == 0) ? rw8[t & 1] : s[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(2);
     // windows: logits = s * dh^-0.5 + rel_h[kh] + rel_w[kw]; the key of element (t, e, half) is static
     if constexpr (!MULTI) {
 #pragma unroll
