@@ -633,9 +633,6 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
 #endif
       return;
     }
-#ifdef VDR_EXPERIMENT_NO_GENERIC
-    return;
-#endif
   }
   __syncthreads();  // every wave is done with the ring: its memory becomes the staging area
   VDR_GSTAMP(4);
