@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--packed", type=int, default=1, help="1: weights in the packed (pair-interleaved) layout, as in the forward")
     ap.add_argument("--gemm-only", action="store_true")
     ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--lds-pad", type=str, default="", help="tuning builds: VDR_GEMM_LDS_PAD values to compare, e.g. 0,40000 (40000: one ring4 workgroup per CU)")
     a = ap.parse_args()
     M, D = a.batch * a.seq, a.dim
     H = D // 64
@@ -57,6 +58,13 @@ def main():
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         Wp = ops.pack_linear_weight(W) if a.packed else W
         for v in [int(s) for s in a.variants.split(",")]:
+            if a.lds_pad:
+                for pad in a.lds_pad.split(","):
+                    def run(x=x, Wp=Wp, b=b, r=r, epi=epi, v=v, out=out, pad=pad):
+                        os.environ["VDR_GEMM_LDS_PAD"] = pad
+                        ops.linear(x, Wp, b, resid=r, epilogue=epi, variant=v, out=out, packed=bool(a.packed))
+                    cases.append((name + "/pad" + pad, N, K, v, run))
+                continue
             cases.append((name, N, K, v, (lambda x=x, Wp=Wp, b=b, r=r, epi=epi, v=v, out=out:
                                           ops.linear(x, Wp, b, resid=r, epilogue=epi, variant=v, out=out, packed=bool(a.packed)))))
     for c in cases:
@@ -87,7 +95,7 @@ def main():
         med, mn = ts[len(ts) // 2], ts[0]
         tf = 2.0 * M * N * K / (med * 1e-3) / 1e12
         res[f"gemm_{name}_v{v}"] = {"ms": med, "min_ms": mn, "TF": tf}
-        print(f"gemm {name:5s} M{M} N{N} K{K} variant {v:4d}: {med:8.4f} ms (min {mn:.4f})  {tf:7.1f} TFLOP/s", flush=True)
+        print(f"gemm {name:14s} M{M} N{N} K{K} variant {v:4d}: {med:8.4f} ms (min {mn:.4f})  {tf:7.1f} TFLOP/s", flush=True)
     if a.gemm_only:
         if a.out:
             json.dump(res, open(a.out, "w"), indent=1)

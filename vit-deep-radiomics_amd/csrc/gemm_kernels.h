@@ -881,6 +881,12 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
       lds += (size_t)BM * 8;
     }
   }
+#ifdef VDR_TUNING
+  {  // tools/: extra dynamic LDS per workgroup (e.g. 40000 on ring4: one workgroup per CU instead of two)
+    const int pad = tuning_env("VDR_GEMM_LDS_PAD", 0);
+    if (pad > 0) lds += (size_t)pad;
+  }
+#endif
 #define VDR_LAUNCH(E)                                                                                  \
   case E: {                                                                                            \
     auto fn = launch_pick<WAVES_M, WAVES_N, PIPE, E>();                                                \
