@@ -224,6 +224,14 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
  * operand loader of the GEMM touches whole lines.  vdr_op_pack_linear_weight converts W [N, K] bf16 (PyTorch layout)
  * into `packed` (N*K bf16, device); N even, K % 32 == 0.  Results are bitwise those of vdr_op_linear. */
 int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream);
+/* vdr_op_linear for a caller whose activation buffer is longer than the M rows it multiplies (the same nn.Linear call
+ * sites, models_archs.py:130-135): `x_rows` >= M rows of x are readable memory.  Tile variant 30 -- the persistent
+ * "stream" kernel the forward uses for its large launches (K >= 768, K % 64 == 0, N % 256 == 0) -- loads whole 128-row
+ * tiles of x and therefore needs x_rows >= M rounded up to 128; rows past M are never stored.  Other variants ignore
+ * x_rows.  Results are bitwise those of vdr_op_linear. */
+int vdr_op_linear_xrows(const void* x, int64_t x_rows, const void* W, const float* bias, const void* resid,
+                        const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
+                        void* stream);
 int vdr_op_linear_packed(const void* x, const void* Wp, const float* bias, const void* resid,
                          const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
                          void* stream);

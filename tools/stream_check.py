@@ -22,15 +22,18 @@ def main():
     g = torch.Generator().manual_seed(3)
     ok = True
     # exact integer cases incl. ragged M, several tiles per workgroup
-    for (M, N, K) in [(128, 256, 704), (333, 768, 768), (1000, 512, 1024), (128 * 300 + 5, 256, 704), (70000, 768, 768)]:
+    for (M, N, K) in [(128, 256, 768), (333, 768, 768), (1000, 512, 1024), (130, 256, 1536), (128 * 300 + 5, 256, 832), (70000, 768, 768)]:
         x = torch.randint(-2, 3, (M, K), generator=g).float()
         W = torch.randint(-2, 3, (N, K), generator=g).float()
         b = torch.randint(-3, 4, (N,), generator=g).float()
-        xd, Wd, bd = x.bfloat16().to(dev), W.bfloat16().to(dev), b.to(dev)
+        Mr = (M + 127) // 128 * 128
+        xpad = torch.full((Mr, K), float("nan"), dtype=torch.bfloat16, device=dev)  # rows past M: readable, never used
+        xpad[:M] = x.bfloat16().to(dev)
+        xd, Wd, bd = xpad[:M], W.bfloat16().to(dev), b.to(dev)
         ref = ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=22)
         pad = torch.full((M + 256, N), 7.0, device=dev, dtype=torch.bfloat16)
         out = pad[:M]
-        ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=30, out=out)
+        ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=30, out=out, x_rows=Mr)
         torch.cuda.synchronize()
         same = torch.equal(out, ref)
         guard = bool((pad[M:] == 7.0).all())

@@ -1520,7 +1520,7 @@ int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const 
 }
 
 static int op_linear_impl(const void* x, const void* W, int packed, const float* bias, const void* resid, const float* gamma,
-                          void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+                          void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream, int64_t x_rows = 0) {
   if (!x || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
   if (epilogue < VDR_EPI_BIAS || epilogue > VDR_EPI_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "epilogue");
   if (epilogue == VDR_EPI_BIAS_RESID && !resid) return fail(nullptr, VDR_ERR_INVALID, "resid required");
@@ -1546,6 +1546,7 @@ static int op_linear_impl(const void* x, const void* W, int packed, const float*
   g.ldc = epilogue == VDR_EPI_SWIGLU ? N / 2 : N;
   g.ldr = g.ldc;
   g.omap = identity_map();
+  g.a_rows = x_rows;
   if (variant == 0)  // library default: what the forward itself would pick for this shape
     variant = gemm_variant_for(N >= 2304 ? VDR_K_GEMM_QKV : VDR_K_GEMM_FC1, M, N);
   const hipError_t e = launch_gemm(g, epilogue, variant, (hipStream_t)stream);
@@ -1560,6 +1561,12 @@ static int op_linear_impl(const void* x, const void* W, int packed, const float*
 int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid, const float* gamma, void* y,
                   int64_t M, int N, int K, int epilogue, int variant, void* stream) {
   return op_linear_impl(x, W, 0, bias, resid, gamma, y, M, N, K, epilogue, variant, stream);
+}
+
+int vdr_op_linear_xrows(const void* x, int64_t x_rows, const void* W, const float* bias, const void* resid, const float* gamma,
+                        void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream) {
+  if (x_rows < M) return fail(nullptr, VDR_ERR_INVALID, "x_rows < M");
+  return op_linear_impl(x, W, 0, bias, resid, gamma, y, M, N, K, epilogue, variant, stream, x_rows);
 }
 
 int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream) {

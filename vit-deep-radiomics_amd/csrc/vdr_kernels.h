@@ -59,6 +59,7 @@ struct GemmArgs {
   int a_rpg = 0;
   int64_t a_gs = 0, a_is = 0;
   int out_f32 = 0;  // C is fp32 (EPI_BIAS / EPI_PATCH)
+  int64_t a_rows = 0;  // rows of A that are readable memory (>= M; 0 = M): the stream kernel (variant 30) loads whole tiles
   // im2col-free patchify (EPI_PATCH on the ring4 variants): A = bf16 NCHW images [B, C, g*p, g*p], M = B*g*g tokens,
   // K = C*p*p with p in {8, 16, 32}; the operand loader gathers 16-byte runs of pixels straight from the images
   int patch_p = 0, patch_g = 0, patch_C = 0;

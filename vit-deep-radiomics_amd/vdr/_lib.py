@@ -52,6 +52,7 @@ SYMBOLS = {
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_op_pack_linear_weight": (_I, [_P, _I, _I, _P, _P]),
     "vdr_op_linear_packed": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "vdr_op_linear_xrows": (_I, [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_prepare_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "vdr_op_prepare_image": (_I, [_P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _I, _P, _P]),
     "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),

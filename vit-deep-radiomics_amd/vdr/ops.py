@@ -37,9 +37,11 @@ def pack_linear_weight(W: torch.Tensor) -> torch.Tensor:
     return Wp
 
 
-def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None, packed=False):
+def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None, packed=False, x_rows=0):
     """x [M,K] bf16, W [N,K] bf16 (for EPI_SWIGLU W/bias must already be gate-pair packed: see pack_w12).
-    packed=True: W is the result of pack_linear_weight (same values, whole-line operand loads)."""
+    packed=True: W is the result of pack_linear_weight (same values, whole-line operand loads).
+    x_rows > 0: x is the head of a buffer with that many readable rows (vdr_op_linear_xrows: what variant 30 needs for a
+    ragged M)."""
     lib = L.load()
     assert x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_contiguous() and W.is_contiguous()
     M, K = x.shape
@@ -47,6 +49,11 @@ def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant
     assert W.shape[1] == K
     if out is None:
         out = torch.empty((M, N // 2 if epilogue == L.EPI_SWIGLU else N), dtype=torch.bfloat16, device=x.device)
+    if x_rows:
+        assert not packed
+        L.check(lib.vdr_op_linear_xrows(x.data_ptr(), x_rows, W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K,
+                                        epilogue, variant, _s(x)))
+        return out
     fn = lib.vdr_op_linear_packed if packed else lib.vdr_op_linear
     L.check(fn(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K, epilogue, variant, _s(x)))
     return out
