@@ -121,6 +121,8 @@ def main():
                     help="after the timed region, also measure the same step with micro-batches of B/2 on two internal HIP "
                          "streams (reported as `two_stream`; never the headline value; off by default so that a rocprof "
                          "summary of the default command holds full-batch launches only)")
+    ap.add_argument("--stream-gemm", action="store_true",
+                    help="vdr_config.stream_gemm = 1: qkv / fc1 on the persistent stream GEMM (A/B; same bits, not the default)")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
     a = ap.parse_args()
@@ -170,7 +172,7 @@ def main():
         ocfg = vo.CONFIGS[a.model]
         weights = vo.make_weights(ocfg, seed=1)
     model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
-                           full_last_block=a.full_last_block)
+                           full_last_block=a.full_last_block, stream_gemm=a.stream_gemm)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
@@ -342,6 +344,7 @@ def main():
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams,
+                          "stream_gemm": bool(a.stream_gemm),
                           "last_block": "every token" if (a.full_last_block or sam or dense) else
                                         "attention on every token; out-projection / norm2 / MLP on the CLS rows only (bitwise the same features)"},
                "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 5
+#define VDR_ABI_VERSION 6
 
 typedef enum {
   VDR_OK = 0,
@@ -115,6 +115,10 @@ typedef struct {
                       /* row-wise and x[:, 0] is all `model(x) -> (logits, cls)` (models_archs.py:24-29) returns; the   */
                       /* features are bitwise those of the full block.  1: every row (A/B, tests, bench.py              */
                       /* --full-last-block).  Other out_modes and post-LN models always run every row.                  */
+  int32_t stream_gemm; /* 1: the qkv and fc1 (GELU) linears of launches with >= 1024 tiles (K >= 768, N % 256 == 0) run on  */
+                      /* the persistent "stream" kernel (csrc/gemm_stream.hip: one workgroup per CU, K steps streaming      */
+                      /* across tile boundaries, epilogue of a tile inside the next tile's MFMAs) instead of the ring4     */
+                      /* tiles; same products in the same order: results are bitwise equal.  0 (default): ring4.           */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

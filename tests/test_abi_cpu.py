@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so or any symbol is missing
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.vdr_abi_version() == 5
+    assert lib.vdr_abi_version() == 6
     assert lib.vdr_kernel_class_name(4) == b"attention"
 
 

@@ -473,6 +473,45 @@ def test_reference_boundary_protocol():
     assert torch.equal(ok, eng.forward(xin, vdr.OUT_CLS))
 
 
+def test_get_dense_descriptor_takes_the_raw_slice():
+    """tfds_dense_descriptor.py:110-139: `get_dense_descriptor(model, img)` is called with the RAW slice -- (h, w) gray or
+    (h, w, 3) colour in [0, 1] -- and runs `prepare_image` itself (gray2rgb + resize to 1024^2, resize to 896^2 for colour).
+    The drop-in must do the same: equal to prepare_image -> encoder / patch_embed -> (h, w, D), bit for bit, and still take
+    an already prepared (3, S, S) image."""
+    import vdr
+    from vdr import prep
+    g = torch.Generator().manual_seed(21)
+    # colour slice -> 896^2 -> the reference's 'dinov2' mode (patch embedding only)
+    cfg = vo.VitCfg(896, 14, 3, 64, 1, 0, 128, pre_ln=False, has_cls=False, has_pos=False)
+    w = vo.make_weights(cfg, seed=4)
+    vc = vdr.VdrConfig(img=896, patch=14, dim=64, heads=1, layers=0, mlp_hidden=128, pre_ln=False, has_cls=False, has_pos=False)
+    model = vdr.VitDescriptorModel(vc, w, "dinov2")
+    rgb = torch.rand(150, 201, 3, generator=g).numpy()
+    f = vdr.get_dense_descriptor(model, rgb)
+    assert f.shape == (64, 64, 64) and f.dtype == np.float32
+    x = prep.prepare_image(rgb)
+    assert x.shape == (1, 3, 896, 896)
+    want = model.patch_embed(x).cpu().numpy()[0].reshape(64, 64, 64)
+    np.testing.assert_array_equal(f, want)
+    np.testing.assert_array_equal(vdr.get_dense_descriptor(model, x[0].cpu().numpy()), want)  # prepared (3, S, S) as before
+    with pytest.raises(ValueError):
+        vdr.get_dense_descriptor(model, rgb[:, :, 0])  # a gray slice prepares to 1024^2: not this model's input
+    # gray slice -> gray2rgb -> 1024^2 -> the reference's 'medsam' mode (image_encoder, [1, C, h, w] -> (h, w, C))
+    cfg2 = vo.VitCfg(1024, 64, 3, 64, 1, 1, 128)
+    w2 = vo.make_weights(cfg2, seed=5)
+    vc2 = vdr.VdrConfig(img=1024, patch=64, dim=64, heads=1, layers=1, mlp_hidden=128)
+    m2 = vdr.VitDescriptorModel(vc2, w2, "medsam")
+    gray = torch.rand(300, 260, generator=g).numpy()
+    f2 = vdr.get_dense_descriptor(m2, gray)
+    assert f2.shape == (16, 16, 64)
+    x2 = prep.prepare_image(gray)
+    assert x2.shape == (1, 3, 1024, 1024)
+    want2 = np.transpose(m2.image_encoder(x2).cpu().numpy()[0], (1, 2, 0))
+    np.testing.assert_array_equal(f2, want2)
+    ref = vo.forward_images(cfg2, w2, x2.cpu())["dense"][0].reshape(16, 16, 64)
+    assert _rel_l2(torch.from_numpy(f2), ref) < 2e-2
+
+
 def test_dinov2_reference_mode_loads_a_real_checkpoint_layout():
     """The reference's 'dinov2' mode (tfds_dense_descriptor.py:70-90, 128-133): torch.hub dinov2_vits14, of which only
     `model.patch_embed(x)` runs, at 896^2.  A state_dict with that checkpoint's REAL key set and shapes (random values;

@@ -535,14 +535,24 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(StreamK p) {
 inline unsigned long long* g_stream_stamps = nullptr;  // tools/micro/stream_stamps.hip
 #endif
 
-hipError_t launch_gemm_stream(const GemmArgs& a, int epi, hipStream_t s) {
-  if (a.K % 64 || a.K / 64 < ST_EU + 1 || a.N % ST_BN || a.M <= 0) return hipErrorInvalidValue;
+static bool stream_shape_ok(const GemmArgs& a, int epi) {
+  if (a.K % 64 || a.K / 64 < ST_EU + 1 || a.N % ST_BN || a.M <= 0) return false;
   // the loader reads whole tiles: the rows of the last tile row past M must be readable memory (the engine's workspace
   // buffers are; GemmArgs::a_rows says how many rows the caller guarantees)
-  if ((a.M + ST_BM - 1) / ST_BM * ST_BM > (a.a_rows > a.M ? a.a_rows : a.M)) return hipErrorInvalidValue;
-  if (a.w_interleaved || a.out_f32 || a.win_ws || a.a_rpg || a.patch_p || a.ln_cpart || a.ln_part) return hipErrorInvalidValue;
-  if (epi != EPI_BIAS && epi != EPI_BIAS_GELU) return hipErrorInvalidValue;
-  if (a.M >= (1 << 30) || a.ldc >= (1 << 24) || a.lda >= (1 << 24) || a.ldw >= (1 << 24)) return hipErrorInvalidValue;
+  if ((a.M + ST_BM - 1) / ST_BM * ST_BM > (a.a_rows > a.M ? a.a_rows : a.M)) return false;
+  if (a.w_interleaved || a.out_f32 || a.win_ws || a.a_rpg || a.patch_p || a.ln_cpart || a.ln_part) return false;
+  if (epi != EPI_BIAS && epi != EPI_BIAS_GELU) return false;
+  if (a.M >= (1 << 30) || a.ldc >= (1 << 24) || a.lda >= (1 << 24) || a.ldw >= (1 << 24)) return false;
+  if (a.ln_stats && !a.colsum) return false;
+  return true;
+}
+
+bool gemm_stream_eligible(const GemmArgs& a, int epi) {
+  return stream_shape_ok(a, epi) && ((a.M + ST_BM - 1) / ST_BM) * (int64_t)(a.N / ST_BN) >= 1024;
+}
+
+hipError_t launch_gemm_stream(const GemmArgs& a, int epi, hipStream_t s) {
+  if (!stream_shape_ok(a, epi)) return hipErrorInvalidValue;
   StreamK k{};
   k.A = (const bf16_t*)a.A;
   k.W = (const bf16_t*)a.W;

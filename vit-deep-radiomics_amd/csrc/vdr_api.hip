@@ -628,9 +628,10 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
   return VDR_OK;
 }
 
+// a_rows: rows of A that are readable memory (the workspace buffers are longer than the M rows in use; 0 = M)
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold(),
-         int64_t lda = 0, int64_t ldr = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
+         int64_t lda = 0, int64_t ldr = 0, int64_t a_rows = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
   GemmArgs g{};
   g.ln_stats = ln.stats;
   g.colsum = ln.colsum;
@@ -657,6 +658,12 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
+  g.a_rows = a_rows;
+  // vdr_config.stream_gemm: the write-once linears of a large launch on the persistent stream kernel (plain weight layout)
+  if (m->cfg.stream_gemm && (cls == VDR_K_GEMM_QKV || cls == VDR_K_GEMM_FC1) && gemm_stream_eligible(g, epi)) {
+    VDR_TRY(launch_gemm(g, epi, 30, s), "gemm_stream");
+    return VDR_OK;
+  }
   VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, M, N), s), "gemm");
   return VDR_OK;
 }
@@ -847,7 +854,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       LnFold cons;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_QKV, M, 3 * D, D, w, &cons))) return rc;
       cons.colsum = L.sqkv;
-      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons)))
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons, 0, 0, w.Mp)))
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -862,7 +869,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons, 0, 0, w.Mp)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod))) return rc;
     }
@@ -875,7 +882,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
       attn_in = w.h;
     }
-    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS)))
+    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, LnFold(), 0, 0, w.Mp)))
       return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -890,7 +897,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.h, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, LnFold(), 0, 0, w.Mp)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
     } else {

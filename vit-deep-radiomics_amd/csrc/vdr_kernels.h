@@ -70,6 +70,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
+// whether variant 30 (gemm_stream.hip) takes this launch and is expected to pay: a write-once epilogue, plain weight layout,
+// K >= 768, N % 256 == 0, A readable up to the tile edge (a_rows), at least 1024 tiles
+bool gemm_stream_eligible(const GemmArgs& a, int epilogue);
 // [N][K] bf16 (row stride ld elements) -> the pair-interleaved weight layout (N even, K % 32 == 0)
 hipError_t launch_w_interleave(const void* src, void* dst, int N, int K, int64_t ld, hipStream_t s);
 

@@ -37,6 +37,7 @@ class VdrConfig:
     ln_fold: bool = True       # pre-LN image models: LayerNorm folded into the qkv / fc1 GEMMs (False: explicit kernel)
     full_last_block: bool = False  # CLS output: True keeps every row of the last block (default: its CLS rows only,
                                # the same features bit for bit; see vdr_config.full_last_block)
+    stream_gemm: bool = False  # qkv / fc1 of large launches on the persistent stream kernel (vdr_config.stream_gemm; same bits)
 
     @property
     def n_patches(self):
@@ -59,6 +60,7 @@ class VdrConfig:
         c.fp8 = int(self.fp8)
         c.no_ln_fold = int(not self.ln_fold)
         c.full_last_block = int(self.full_last_block)
+        c.stream_gemm = int(self.stream_gemm)
         return c
 
 

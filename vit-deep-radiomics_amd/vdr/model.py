@@ -95,7 +95,7 @@ class VitDescriptorModel:
 
 
 def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0,
-               fp8: int = 0, full_last_block: bool = False):
+               fp8: int = 0, full_last_block: bool = False, stream_gemm: bool = False, ln_fold: bool = True):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
     torch.load(weights_only=True).  weights: the same dict passed directly.
@@ -105,7 +105,8 @@ def load_model(model_name: str, model_path=None, weights=None, device=None, micr
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
     cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams,
-                       "fp8": int(fp8) or int(ARCHS[model_name].fp8), "full_last_block": bool(full_last_block)})
+                       "fp8": int(fp8) or int(ARCHS[model_name].fp8), "full_last_block": bool(full_last_block),
+                       "stream_gemm": bool(stream_gemm), "ln_fold": bool(ln_fold)})
     if weights is None:
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
@@ -118,13 +119,31 @@ def load_model(model_name: str, model_path=None, weights=None, device=None, micr
 
 
 def get_dense_descriptor(model, img) -> np.ndarray:
-    """R2 wrapper with the reference's single-image contract: img (3,H,W) or (1,3,H,W) array/tensor,
-    already resized to the model's input side, values in [0,1]  ->  (h, w, D) float32 numpy.
-    (The skimage resize of prepare_image stays upstream: SURVEY.md §8 row f-3.)"""
-    t = torch.as_tensor(img, dtype=torch.float32)
-    if t.dim() == 3:
-        t = t.unsqueeze(0)
-    t = t.to(model.device)
+    """R2: the reference's function (tfds_dense_descriptor.py:110-139), same argument, same result layout.
+    img: the RAW slice exactly as the reference passes it -- (h, w) gray or (h, w, 3) colour, values in [0, 1]; it is
+    prepared here as `prepare_image` does (tfds_dense_descriptor.py:30-48: gray2rgb + resize to 1024^2 for gray,
+    resize to 896^2 for colour, CHW, float32, on the device: vdr.prep.prepare_image) and run through
+    `model.image_encoder` ('medsam') or `model.patch_embed` (anything else), returning (h, w, D) float32 numpy.
+    Also accepted, for callers that prepared the image themselves: a (3, S, S) or (1, 3, S, S) array / tensor with S
+    the model's input side (taken as it is)."""
+    from . import prep
+    t = torch.as_tensor(img)
+    side = model.cfg.img
+    prepared = t.dim() == 4 or (t.dim() == 3 and t.shape[0] == 3 and tuple(t.shape[1:]) == (side, side))
+    if prepared:
+        t = t.to(torch.float32)
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        t = t.to(model.device)
+    else:
+        if t.dim() not in (2, 3) or (t.dim() == 3 and t.shape[2] != 3):
+            raise ValueError(f"get_dense_descriptor: a raw (h, w) / (h, w, 3) slice or a prepared (3, {side}, {side}) image, "
+                             f"got {tuple(t.shape)}")
+        t = prep.prepare_image(t, device=model.device)  # [1, 3, 1024 | 896, .] float32 on the device
+        if t.shape[-1] != side:
+            raise ValueError(f"prepare_image gives a {t.shape[-1]}^2 image for a {'gray' if torch.as_tensor(img).dim() == 2 else 'colour'} "
+                             f"slice, model '{model.model_name}' takes {side}^2 (the reference pairs gray slices with "
+                             "'medsam' and colour slices with 'dinov2')")
     if model.model_name == "medsam":
         f = model.image_encoder(t).cpu().numpy()
         return np.transpose(np.squeeze(f), (1, 2, 0))
