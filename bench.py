@@ -121,6 +121,14 @@ def main():
                     help="after the timed region, also measure the same step with micro-batches of B/2 on two internal HIP "
                          "streams (reported as `two_stream`; never the headline value; off by default so that a rocprof "
                          "summary of the default command holds full-batch launches only)")
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="N > 1: micro-batches per step whose gathers overlap the next micro-batch's kernels (0 = by message size: "
+                         "1 for the CLS matrix, 4 for dense descriptors)")
+    ap.add_argument("--gather-mode", choices=["auto", "mesh", "collective"], default="auto",
+                    help="N > 1: mesh = point-to-point sends into the peers' row slices (batch_isend_irecv over the xGMI mesh), "
+                         "collective = all_gather_into_tensor; auto = mesh above 8 MB per rank")
+    ap.add_argument("--dense-dtype", choices=["bf16", "fp32"], default="bf16",
+                    help="--out dense: dtype of the gathered per-patch descriptors (BASELINE config 4 states bf16)")
     ap.add_argument("--stream-gemm", action="store_true",
                     help="vdr_config.stream_gemm = 1: qkv / fc1 on the persistent stream GEMM (A/B; same bits, not the default)")
     ap.add_argument("--clean-timing", action="store_true",
@@ -184,15 +192,24 @@ def main():
         D = ocfg.grid * ocfg.grid * ocfg.out_chans
     elif dense:  # per-patch token descriptors [N, n, D] fp32, one row per image for the gather
         D = (ocfg.img // ocfg.patch) ** 2 * ocfg.dim
-    feats = torch.empty((total, D), dtype=torch.float32, device=dev)  # final row-ordered [N, D] matrix
-    # single GPU: the forward writes the matrix directly; multi GPU: each rank's rows go to a send buffer
-    # and ONE all-gather lays them out in rank (= dataset) order
-    mine = feats if world == 1 else torch.empty((B, D), dtype=torch.float32, device=dev)
+    # final row-ordered [N, D] matrix: fp32 CLS features (what umap_cls_token.py:139 / embedding_classifier.py:102 read);
+    # dense per-patch descriptors in bf16 (BASELINE config 4) unless --dense-dtype fp32
+    fdt = torch.bfloat16 if (dense and a.dense_dtype == "bf16") else torch.float32
+    feats = torch.empty((total, D), dtype=fdt, device=dev)
+    out_mode = vdr.OUT_ENCODER if sam else (vdr.OUT_DENSE if dense else vdr.OUT_CLS)
+    # Every rank's forward writes STRAIGHT into its row slice of the matrix.  N > 1: micro-batch by micro-batch, each
+    # finished micro-batch going to the peers on a side stream while the next one computes (vdr.dist.OverlappedGather)
+    og = None
+    if world > 1:
+        from vdr.dist import OverlappedGather
+        og = OverlappedGather(feats, total, chunks=a.gather_chunks, mode=a.gather_mode)
+    mine = feats if world == 1 else feats[rank * B:(rank + 1) * B]
 
     def step():
-        eng.forward_into(images, mine, vdr.OUT_ENCODER if sam else (vdr.OUT_DENSE if dense else vdr.OUT_CLS))  # this rank's rows of the gather buffer
-        if world > 1:
-            dist.all_gather_into_tensor(feats, mine)
+        if og is None:
+            eng.forward_into(images, mine, out_mode)
+        else:
+            og.run(lambda x0, x1, rows: eng.forward_into(images[x0:x1], rows, out_mode))
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -285,11 +302,28 @@ def main():
         except Exception as e:  # never let the side measurement break the benchmark line
             full = {"error": str(e)[:200]}
 
+    # N > 1, informational: what the transfers of a step occupy on the side stream, and the same K steps WITHOUT any
+    # transfer (the N = 1-equivalent rate of this rank: what the overlap is measured against)
+    gather = None
+    if og is not None:
+        step()
+        sync()
+        gms = og.last_gather_ms()
+        sync()
+        tc0 = time.perf_counter()
+        for _ in range(a.steps):
+            eng.forward_into(images, mine, out_mode)
+        sync()
+        dtc = time.perf_counter() - tc0
+        gather = {"mode": og.mode, "chunks": og.chunks, "bytes_per_rank": int(B * D * feats.element_size()),
+                  "side_stream_ms_per_step": None if gms is None else round(gms, 3),
+                  "compute_only_ms_per_step": round(dtc / a.steps * 1e3, 3),
+                  "n1_equivalent_images_per_s_per_gpu": round(B * a.steps / dtc, 1)}
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
-    assert torch.isfinite(feats).all()
+    assert torch.isfinite(feats.float()).all()
 
     if rank == 0:
         flops_ref = so.flops_per_image(ocfg) if sam else vo.flops_per_image(ocfg)  # every token of every block
@@ -340,14 +374,15 @@ def main():
                "dtype": "fp8 (MX e4m3 qkv/fc1/fc2, bf16 elsewhere)" if a.fp8 else "bf16", "data": "synthetic",
                "config": {"workload": (f"medsam (SAM ViT-B image encoder) {ocfg.img}^2 fp32 in / bf16 compute, batch {B}/GPU -> "
                                        f"[{total},64,64,256] fp32" if sam else
-                                       f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, {'dense per-patch descriptors' if dense else 'CLS-token extraction'} -> [{total},{D}] fp32")
+                                       f"{a.model} {ocfg.img}^2 {'MX-fp8 weights' if a.fp8 else 'bf16'}, batch {B}/GPU, {'dense per-patch descriptors' if dense else 'CLS-token extraction'} -> [{total},{D}] {'bf16' if fdt == torch.bfloat16 else 'fp32'}")
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams,
                           "stream_gemm": bool(a.stream_gemm),
                           "last_block": "every token" if (a.full_last_block or sam or dense) else
                                         "attention on every token; out-projection / norm2 / MLP on the CLS rows only (bitwise the same features)"},
-               "feature_GBps": round(total * D * 4 * a.steps / dt / 1e9, 4),
+               "feature_GBps": round(total * D * feats.element_size() * a.steps / dt / 1e9, 4),
+               "gather": gather,
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
                "roofline": roof, "kernels": kern, "two_stream": two, "full_last_block": full}
         if not a.no_cpu_baseline and world == 1 and not sam:

@@ -8,6 +8,7 @@
 // Workgroups that share blockIdx % 8 (one XCD under round-robin placement) read the same row window, so the source
 // is served by that XCD's L2 after the first touch (window: `rows` x K x 2 B, default 1024 x 768 = 1.5 MB per XCD).
 // Reports GB/s per CU for 1 or 2 workgroups per CU of 4 / 8 / 16 waves.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/micro/glds_shape.hip -o tools/micro/glds_shape   (the binary is not tracked)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summaries for the benchmark lines recorded under profiles/ (run on the GPU box):
-#   bash tools/prof_round.sh [names...]   default: all
+#   bash tools/prof_round.sh [names...]   default: all (names: vitb medsam_b1 medsam_b16 vitl_dense vitg_fp8 vitg_bf16)
 set -e
+WANT="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/prof
 run() {  # name, bench args...
@@ -12,11 +13,9 @@ run() {  # name, bench args...
   rm -rf gpurun_out/prof/$name
   tail -1 gpurun_out/prof/$name.json.log | cut -c1-200
 }
-want() { [ $# -eq 0 ] && return 0; for n in "$@"; do [ "$n" = "$NAME" ] && return 0; done; return 1; }
 for spec in "vitb" "medsam_b1 --model medsam --batch 1" "medsam_b16 --model medsam --batch 16 --steps 10" \
             "vitl_dense --model vit_large14_336 --batch 64 --out dense --steps 10" \
             "vitg_fp8 --model dinov2_giant14_224 --batch 32 --fp8 --steps 10" "vitg_bf16 --model dinov2_giant14_224 --batch 32 --steps 10"; do
-  set -- $spec_args
   NAME=${spec%% *}
   ARGS=${spec#"$NAME"}
   if [ -z "$WANT" ] || echo " $WANT " | grep -q " $NAME "; then run $NAME $ARGS; fi

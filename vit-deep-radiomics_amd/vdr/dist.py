@@ -8,6 +8,7 @@ the 1-rank result.
 from __future__ import annotations
 
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -27,9 +28,11 @@ def free_port() -> int:
 def launch_ranks(script: str, nproc: int, args=(), env=None, timeout=None) -> int:
     """Start `nproc` fresh rank processes of `script` on this node (one per GPU) and wait for them:
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script args`.
-    The ranks are CHILD processes created with subprocess (fork + exec of a new interpreter); the caller must not
-    have touched the GPU yet and is never replaced itself -- a process that has initialised HIP is not re-exec'd.
-    stdout / stderr of the ranks pass through.  Returns the launcher's exit code (0 = every rank exited 0)."""
+    The ranks are CHILD processes created with subprocess (fork + exec of a NEW interpreter: the caller is never replaced
+    and may itself have initialised the GPU -- nothing of its state reaches the children).  The launcher runs in its own
+    session: on `timeout` the whole process group (launcher + ranks) gets SIGTERM, then SIGKILL, so no rank is left
+    behind holding a GPU.  stdout / stderr of the ranks pass through.  Returns the launcher's exit code (0 = every rank
+    exited 0; 124 after a timeout)."""
     e = dict(os.environ if env is None else env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
         e.pop(k, None)  # a stale rendezvous in the caller's environment must not leak into the children
@@ -37,7 +40,21 @@ def launch_ranks(script: str, nproc: int, args=(), env=None, timeout=None) -> in
     e.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *[str(a) for a in args]]
-    return subprocess.run(cmd, env=e, timeout=timeout).returncode
+    proc = subprocess.Popen(cmd, env=e, start_new_session=True)
+    try:
+        return proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 10)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
 
 
 def init_from_env(backend: str = "nccl", device=None):
@@ -91,3 +108,152 @@ def extract_features_sharded(extract_fn, images_local: torch.Tensor, total_rows:
     """extract_fn(images_local) -> [rows_local, D] on this rank's device; returns the full [N, D]
     matrix on every rank (the array umap_cls_token.py:139 stacks / embedding_classifier.py:102 reads)."""
     return all_gather_rows(extract_fn(images_local), total_rows, group)
+
+
+# ---- the step that hides its gather (SURVEY.md 8e; reference consumers: umap_cls_token.py:133-139) ------------------------
+MESH_THRESHOLD_BYTES = 8 << 20  # per-rank message above which "auto" takes the full-mesh point-to-point path
+
+
+def gather_plan(rows_local_bytes: int, chunks: int = 0, mode: str = "auto"):
+    """(chunks, mode) for a per-rank message of that many bytes: small messages (the [B, D] CLS matrix: < 1 MB per
+    rank) go out as ONE collective after the forward -- splitting the forward would cost more than the gather takes;
+    large ones (dense per-patch descriptors: 75 MB per rank and step at BASELINE config 4) are cut in 4 micro-batches
+    whose gathers run on a side stream under the next micro-batch's kernels, point to point over the full xGMI mesh."""
+    big = rows_local_bytes > MESH_THRESHOLD_BYTES
+    if chunks <= 0:
+        chunks = 4 if big else 1
+    if mode == "auto":
+        mode = "mesh" if big else "collective"
+    if mode not in ("mesh", "collective"):
+        raise ValueError(f"gather mode {mode!r}: 'auto', 'mesh' or 'collective'")
+    return chunks, mode
+
+
+class OverlappedGather:
+    """One data-parallel extraction step: this rank's forward writes its rows STRAIGHT into its slice of the final
+    row-ordered [N, ...] matrix, micro-batch by micro-batch, and every finished micro-batch is sent to the peers while the
+    next one computes.
+
+    mode "collective": all_gather_into_tensor per micro-batch into a [world, rows, ...] staging buffer + one strided
+        device copy into the peers' row slices (RCCL picks the algorithm; equal shards only);
+    mode "mesh": every rank posts, per micro-batch, one send of its rows to each peer and one receive from each peer
+        DIRECTLY into that peer's row slice of the final matrix (batch_isend_irecv: RCCL runs the 2 (world - 1) transfers
+        of a group concurrently, one per xGMI link of the point-to-point mesh; no staging, ragged shards welcome).
+    Pure copies either way: the matrix is bitwise the 1-rank result.
+
+    On a GPU the transfers are issued from a side stream that waits for the micro-batch's forward only (an event), so the
+    compute stream never waits for a transfer until `finish()`; on CPU tensors (gloo, the tests) the same calls run in
+    order.  `gather_ms` (GPU) is the time the transfers of the last step occupied the side stream."""
+
+    def __init__(self, feats: torch.Tensor, total_rows: int, chunks: int = 0, mode: str = "auto", group=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        assert feats.shape[0] == total_rows and feats.is_contiguous()
+        self.feats, self.total = feats, total_rows
+        self.bounds = [shard_bounds(total_rows, r, self.world) for r in range(self.world)]
+        lo, hi = self.bounds[self.rank]
+        row_bytes = feats[0].numel() * feats.element_size() if total_rows else 0
+        self.chunks, self.mode = gather_plan((hi - lo) * row_bytes, chunks, mode)
+        # (the same count on every rank whatever its own shard holds: the ranks pair their transfers per micro-batch)
+        self.chunks = max(1, min(self.chunks, max(b - a for a, b in self.bounds) or 1))
+        sizes = {b - a for a, b in self.bounds}
+        if self.mode == "collective" and len(sizes) != 1:
+            self.mode = "mesh"  # ragged shards: the point-to-point path needs no padding
+        self.cuda = feats.is_cuda
+        self.side = torch.cuda.Stream(device=feats.device) if self.cuda and self.world > 1 else None
+        self._stage = None
+        self._work, self._events = [], []
+        self.gather_ms = None
+
+    def my_rows(self):
+        return self.bounds[self.rank]
+
+    def chunk_bounds(self, r: int, c: int):
+        """rows [lo, hi) of the final matrix that are micro-batch c of rank r"""
+        lo, hi = self.bounds[r]
+        a, b = shard_bounds(hi - lo, c, self.chunks)
+        return lo + a, lo + b
+
+    def run(self, forward_rows) -> torch.Tensor:
+        """forward_rows(a, b, out) computes this rank's local images [a, b) into `out` (= their rows of the final
+        matrix, a view); returns the complete matrix."""
+        lo, _ = self.my_rows()
+        t0 = t1 = None
+        for c in range(self.chunks):
+            a, b = self.chunk_bounds(self.rank, c)
+            if b > a:
+                forward_rows(a - lo, b - lo, self.feats[a:b])
+            if self.world == 1:
+                continue
+            if self.side is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    if c == 0:
+                        t0 = torch.cuda.Event(enable_timing=True)
+                        t0.record()
+                    self._post(c)
+                    if c == self.chunks - 1:
+                        t1 = torch.cuda.Event(enable_timing=True)
+                        t1.record()
+            else:
+                self._post(c)
+        self.finish()
+        if t0 is not None and t1 is not None:
+            self._events = [(t0, t1)]
+        return self.feats
+
+    def _post(self, c: int):
+        if self.mode == "mesh":
+            ops = []
+            for k in range(1, self.world):  # staggered partners: every rank talks to a different peer in round k
+                dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
+                a, b = self.chunk_bounds(self.rank, c)
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, self.feats[a:b], dst, self.group))
+                a, b = self.chunk_bounds(src, c)
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, self.feats[a:b], src, self.group))
+            if ops:
+                self._work += dist.batch_isend_irecv(ops)
+            return
+        a, b = self.chunk_bounds(self.rank, c)
+        n = b - a
+        if n == 0:
+            return
+        if self.chunks == 1:  # the whole shard at once: the in-place collective (input = this rank's slice of the output)
+            w = dist.all_gather_into_tensor(self.feats, self.feats[a:b], group=self.group, async_op=True)
+            w.wait()
+            return
+        if self._stage is None or self._stage.shape[1] < n:
+            mx = max(self.chunk_bounds(self.rank, cc)[1] - self.chunk_bounds(self.rank, cc)[0] for cc in range(self.chunks))
+            self._stage = torch.empty((self.world, mx) + tuple(self.feats.shape[1:]), dtype=self.feats.dtype, device=self.feats.device)
+        stage = self._stage[:, :n] if self._stage.shape[1] == n else None
+        if stage is None:  # (the last micro-batch of an uneven split: a contiguous staging view of its own size)
+            stage = torch.empty((self.world, n) + tuple(self.feats.shape[1:]), dtype=self.feats.dtype, device=self.feats.device)
+        w = dist.all_gather_into_tensor(stage.view((self.world * n,) + tuple(self.feats.shape[1:])), self.feats[a:b], group=self.group,
+                                        async_op=True)
+        if self.side is None:
+            w.wait()
+        else:
+            w.wait()  # (orders the side stream behind the collective; the compute stream is not involved)
+        for r in range(self.world):
+            if r != self.rank:
+                ra, rb = self.chunk_bounds(r, c)
+                self.feats[ra:rb].copy_(stage[r])
+
+    def finish(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+        if self.side is not None:
+            torch.cuda.current_stream(self.feats.device).wait_stream(self.side)
+
+    def last_gather_ms(self):
+        """time between the first transfer's start and the last transfer's end on the side stream (call after a device
+        synchronisation); None on CPU / world 1"""
+        if not self._events:
+            return None
+        t0, t1 = self._events[0]
+        return t0.elapsed_time(t1)
