@@ -30,7 +30,9 @@
  *     (vdr_set_weight, vdr_finalize) are synchronous;
  *   - a handle's calls run on the handle's device whatever device is current, and
  *     leave the caller's current device unchanged;
- *   - a handle is bound to one device and is not thread-safe (one per rank).
+ *   - a handle is bound to one device and is not thread-safe (one per rank); several handles on DIFFERENT devices of one
+ *     process are supported (the kernels' one-time launch state -- > 64 KB dynamic-LDS opt-in, occupancy, CU count -- is
+ *     kept per device), each used from one thread at a time;
  *   - there is NO CPU path in this library: with no HIP device every compute
  *     call fails with VDR_ERR_NO_DEVICE.
  */

@@ -578,19 +578,16 @@ template <int NT, bool LOADER>
 static hipError_t launch_persist(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(2 * NT * 32 * 128);
   auto fn = attn_persist_kernel<NT, LOADER>;
-  static bool attr_set = false;  // per instantiation: raised once, not per launch
-  if (!attr_set) {
+  static PerDeviceFlag attr;  // per instantiation and device: raised once, not per launch
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
+  if (!attr.done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr.done[dev] = true;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  int n_cu = device_cu_count(dev);
+  if (n_cu <= 0) n_cu = 256;
   const int n_items = batch * k.heads;
   const int grid = n_items < n_cu ? n_items : n_cu;
   hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(LOADER ? 512 : 448), lds, s, k, n_items);
@@ -602,11 +599,13 @@ static hipError_t launch_nt(const AttnK& k, int batch, hipStream_t s) {
   constexpr size_t image = 2 * (size_t)NT * 32 * 128;       // K image + V image
   const size_t lds = image;
   auto fn = attn_kernel<NT>;
-  static bool attr_set = false;  // per instantiation: raised once, not per launch
-  if (image > 65536 && !attr_set) {
+  static PerDeviceFlag attr;  // per instantiation and device: raised once, not per launch
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
+  if (image > 65536 && !attr.done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)image);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr.done[dev] = true;
   }
   const int nqt = (k.seq + 31) / 32;
   const dim3 grid((unsigned)(batch * k.heads * ((nqt + k.qt_per_block - 1) / k.qt_per_block)));

@@ -353,11 +353,13 @@ template <int NT, int S, bool MULTI>
 static hipError_t launch_rp(const AttnRK& k, int batch, hipStream_t s) {
   constexpr size_t lds = (MULTI ? 2 : 1) * 2 * (size_t)NT * 32 * 128;  // (K image + V image) x 1 or 2 buffers
   auto fn = attn_relpos_kernel<NT, S, MULTI>;
-  static bool attr_set = false;  // per instantiation: raised once, not per launch
-  if (lds > 65536 && !attr_set) {
+  static PerDeviceFlag attr;  // per instantiation and device: raised once, not per launch
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
+  if (lds > 65536 && !attr.done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr.done[dev] = true;
   }
   const int nqt = (k.seq + 31) / 32;
   const dim3 grid((unsigned)(batch * k.heads * ((nqt + k.qt_per_block - 1) / k.qt_per_block)));

@@ -855,6 +855,8 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   if (PIPE >= 50 && a.a_rpg) return hipErrorInvalidValue;  // the two-stride A gather stays on ring3
 
   dim3 grid((unsigned)k.nwg), block(NWV * 64);
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
   bool persistent = PIPE >= 50 && epi == EPI_BIAS_RESID;  // (see gemm_ring4p_kernel)
 #ifdef VDR_TUNING
   {
@@ -892,25 +894,26 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     auto fn = launch_pick<WAVES_M, WAVES_N, PIPE, E>();                                                \
     if (persistent && launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>() != fn) {                     \
       auto pfn = launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>();                                  \
-      static int slots = 0; /* workgroups of this instantiation the chip holds at once */              \
+      static int slots_dev[VDR_MAX_DEVICES] = {}; /* workgroups of this instantiation the chip holds at once */ \
+      int& slots = slots_dev[dev];                                                                     \
       if (!slots) {                                                                                    \
-        int dev = 0, per_cu = 0;                                                                       \
-        hipDeviceProp_t prop;                                                                          \
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||    \
+        int per_cu = 0;                                                                                \
+        const int n_cu = device_cu_count(dev);                                                         \
+        if (n_cu <= 0 ||                                                                               \
             hipFuncSetAttribute((const void*)pfn, hipFuncAttributeMaxDynamicSharedMemorySize,          \
                                 (int)(lds > 65536 ? lds : 65536)) != hipSuccess ||                     \
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)pfn, (int)block.x, lds) != hipSuccess || \
             per_cu <= 0)                                                                               \
           return hipErrorUnknown;                                                                      \
-        slots = per_cu * prop.multiProcessorCount;                                                     \
+        slots = per_cu * n_cu;                                                                         \
       }                                                                                                \
       if (k.nwg > slots) {                                                                             \
         fn = pfn;                                                                                      \
         grid = dim3((unsigned)slots);                                                                  \
       }                                                                                                \
     }                                                                                                  \
-    static size_t lds_set[2] = {0, 0}; /* per kernel: the attribute is raised once, not per launch */  \
-    size_t& lset = lds_set[grid.x != (unsigned)k.nwg];                                                 \
+    static size_t lds_set[VDR_MAX_DEVICES][2] = {}; /* per kernel and device: the attribute is raised once, not per launch */ \
+    size_t& lset = lds_set[dev][grid.x != (unsigned)k.nwg];                                            \
     if (lds > 65536 && lds > lset) {                                                                   \
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                          (int)lds);                                                    \

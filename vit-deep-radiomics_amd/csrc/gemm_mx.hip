@@ -264,14 +264,16 @@ static hipError_t launch_mx_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   const size_t stg = (size_t)NW * 32 * 272;
   const size_t lds = ring > stg ? ring : stg;
   const dim3 grid((unsigned)nwg), block(NW * 64);
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
 #define VDR_LAUNCH_MX(E)                                                                                          \
   case E: {                                                                                                       \
     auto fn = gemm_mx_kernel<WAVES_M, WAVES_N, NST, E>;                                                           \
-    static bool attr_set = false; /* per instantiation: lds is a compile-time constant of it */                   \
-    if (lds > 65536 && !attr_set) {                                                                               \
+    static PerDeviceFlag attr; /* per instantiation and device: lds is a compile-time constant of it */           \
+    if (lds > 65536 && !attr.done[dev]) {                                                                         \
       hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
       if (e != hipSuccess) return e;                                                                              \
-      attr_set = true;                                                                                            \
+      attr.done[dev] = true;                                                                                      \
     }                                                                                                             \
     hipLaunchKernelGGL(fn, grid, block, lds, s, k);                                                               \
     break;                                                                                                        \

@@ -589,22 +589,18 @@ hipError_t launch_gemm_stream(const GemmArgs& a, int epi, hipStream_t s) {
   k.stamps = g_stream_stamps;
 #endif
 
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  static int n_cu[64] = {};
-  if (!n_cu[dev]) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu[dev] = prop.multiProcessorCount;
-  }
-  const int grid = k.ntiles < n_cu[dev] ? k.ntiles : n_cu[dev];
+  const int dev = current_device_index();
+  if (dev < 0) return hipErrorInvalidDevice;
+  const int n_cu = device_cu_count(dev);
+  if (n_cu <= 0) return hipErrorUnknown;
+  const int grid = k.ntiles < n_cu ? k.ntiles : n_cu;
 #define ST_LAUNCH2(E, F, NTV)                                                                                            \
   {                                                                                                                 \
-    static bool attr[64] = {};                                                                                      \
-    if (!attr[dev]) {                                                                                               \
+    static PerDeviceFlag attr;                                                                                      \
+    if (!attr.done[dev]) {                                                                                               \
       hipError_t e = hipFuncSetAttribute((const void*)gemm_stream_kernel<E, F, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS); \
       if (e != hipSuccess) return e;                                                                                \
-      attr[dev] = true;                                                                                             \
+      attr.done[dev] = true;                                                                                           \
     }                                                                                                               \
     hipLaunchKernelGGL((gemm_stream_kernel<E, F, NTV>), dim3(grid), dim3(512), ST_LDS, s, k);                       \
   }

@@ -55,6 +55,11 @@ VDR_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // ulp = 2e-3 relative), 55 x coarser than the approximation, so results are those of the exact function to one bf16
 // rounding.  Cost: 10 VALU instructions + one v_exp_f32 per value; the earlier Abramowitz-Stegun 7.1.26 form (1.5e-7
 // absolute) took 14 + v_rcp + v_exp, and the GELU is VALU-throughput bound: 0.05 ms of a 0.27 ms fc1 launch.
+// NaN: v_min / v_max return their non-NaN operand, so gelu_erf(NaN) = -3e-8, not NaN (torch's gelu propagates it).  A
+// NaN-preserving form needs a compare + select (2 more instructions per value) -- x + |x| for 2 max(x, 0) breaks -inf,
+// 0 * x breaks +inf -- in an epilogue that is bound by vector issue.  Inside a transformer block the residual stream
+// carries a NaN row on regardless; the one consumer without a residual, the classifier heads (vdr/model.py _MlpHead),
+// hands non-finite feature rows on itself.
 VDR_DEV float gelu_erf(float x) {
   // (v_min / v_max written out: fminf / fmaxf make hipcc canonicalise their operands first, one more v_max each)
   float a, relu;

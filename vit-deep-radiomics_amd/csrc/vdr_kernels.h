@@ -13,6 +13,28 @@
 
 namespace vdr {
 
+// One-time launch state of a kernel instantiation is PER DEVICE: hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in),
+// occupancy and CU counts belong to the device that is current when they are set / read.  A handle runs on its own
+// device whatever device the caller has current (include/vdr.h), so a second handle on another GPU of the same process
+// must find its own flags, not the first device's.
+constexpr int VDR_MAX_DEVICES = 64;
+static inline int current_device_index() {
+  int d = -1;
+  return hipGetDevice(&d) == hipSuccess && d >= 0 && d < VDR_MAX_DEVICES ? d : -1;
+}
+struct PerDeviceFlag {
+  bool done[VDR_MAX_DEVICES] = {};
+};
+static inline int device_cu_count(int dev) {  // 0 on failure
+  static int n[VDR_MAX_DEVICES] = {};
+  if (dev < 0 || dev >= VDR_MAX_DEVICES) return 0;
+  if (!n[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+  }
+  return n[dev];
+}
+
 // row r of a compact [R, *] view  <->  row (r / rpg) * gstride + off + (r % rpg) of a token buffer
 struct RowMap {
   int rpg;

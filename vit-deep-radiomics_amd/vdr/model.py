@@ -244,7 +244,13 @@ class _MlpHead:
     def __call__(self, x):
         from . import ops
         hid = ops.linear(x.to(torch.bfloat16).contiguous(), self.w1, self.b1, epilogue=L.EPI_BIAS_GELU)
-        return ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.n].float()
+        out = ops.linear(hid, self.w2, self.b2, epilogue=L.EPI_BIAS)[:, : self.n].float()
+        # The device erf-GELU (csrc/vdr_dev.h: max(x, 0) - a 2^Q(a), a = min(|x|, 5.7)) maps a NaN pre-activation to
+        # -3e-8 -- v_min / v_max return their non-NaN operand, and a NaN-preserving form costs the VALU-bound fc1 epilogue
+        # of the ViTs one to two more instructions per value.  Inside a transformer block the residual stream carries the
+        # NaN on; this head has no residual, so a non-finite feature row is handed on here, as torch's gelu would:
+        bad = ~torch.isfinite(x.float()).all(dim=-1, keepdim=True)
+        return torch.where(bad, torch.full_like(out, float("nan")), out)
 
 
 class _CrossAttentionCls:
