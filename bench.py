@@ -345,20 +345,24 @@ def main():
         dv = prof_dom[dom]
         ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r02_pmc_traffic.*): PMC counters cannot be
-        # collected from inside this process, so the number is the profiled one for the same launch shape
-        traffic = None
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r03_pmc_traffic.*): PMC counters cannot be
+        # collected from inside this process, so the number is the profiled one for the same launch shape -- and only
+        # while the kernels are the profiled ones: the file carries vdr.source_id() (sha256 over csrc/) of its run
+        traffic, traffic_note = None, "profiles/r03_pmc_traffic.txt"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS)", "attention": "attention"}.get(dom)
-            if key in pm and a.model == "vit_base16_224" and B == 256:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS)", "attention": "attention",
+                   "gemm_fc2": "gemm_fc2 (EPI_BIAS_RESID, K > N)", "gemm_proj": "gemm_proj (EPI_BIAS_RESID, K = N)"}.get(dom)
+            if pm.get("_source_id") != vdr.source_id():
+                traffic_note = f"dropped: profiles/r03_pmc_traffic.json was taken with kernel sources {pm.get('_source_id')}, this run has {vdr.source_id()}"
+            elif key in pm and a.model == "vit_base16_224" and B == 256 and not a.stream_gemm:
                 traffic = round((pm[key]["read_mb_corrected"] + pm[key]["write_mb"]) * 1e6)
-        except Exception:
-            traffic = None
+        except Exception as e:
+            traffic, traffic_note = None, f"unavailable: {type(e).__name__}"
         # fp8 run: the qkv / fc1 / fc2 GEMMs are priced against the dense fp8 peak, everything else against bf16
         peak = PEAK_FP8_TFLOPS if a.fp8 and dom in ("gemm_qkv", "gemm_fc1", "gemm_fc2") else PEAK_BF16_TFLOPS
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r02_pmc_traffic.txt)",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC passes: " + traffic_note + ")",
                 "avg_launch_ms": round(dv["ms"] / dv["launches"], 4),
                 "flops_per_launch": dv["flops"] / dv["launches"],
                 "whole_forward_frac": round(flops_img * B * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -7,10 +7,11 @@ import re
 import sys
 from collections import defaultdict
 
-CLASSES = [  # (label, regex on the demangled kernel name)
-    ("gemm_fc1 (EPI_BIAS_GELU)", r"gemm_ring\dp?_kernel<[^>]*, 1>"),
-    ("gemm_proj+fc2 (EPI_BIAS_RESID)", r"gemm_ring\dp?_kernel<[^>]*, 2>"),
-    ("gemm_qkv (EPI_BIAS)", r"gemm_ring\dp?_kernel<[^>]*, 0>"),
+CLASSES = [  # (label, regex on the demangled kernel name: gemm_ring4[p]_kernel<WAVES_M, WAVES_N, EPI, TAG>; TAG 1 = K > N)
+    ("gemm_fc1 (EPI_BIAS_GELU)", r"gemm_ring\dp?_kernel<\d+, \d+, 1, \d+>"),
+    ("gemm_proj (EPI_BIAS_RESID, K = N)", r"gemm_ring\dp?_kernel<\d+, \d+, 2, 0>"),
+    ("gemm_fc2 (EPI_BIAS_RESID, K > N)", r"gemm_ring\dp?_kernel<\d+, \d+, 2, 1>"),
+    ("gemm_qkv (EPI_BIAS)", r"gemm_ring\dp?_kernel<\d+, \d+, 0, \d+>"),
     ("attention", r"attn_(persist_)?kernel"),
     ("ln_finalize", r"ln_finalize_kernel"),
 ]
@@ -18,6 +19,8 @@ CLASSES = [  # (label, regex on the demangled kernel name)
 M = 50432
 ALG = {"gemm_fc1 (EPI_BIAS_GELU)": (M * 768 + 3072 * 768 + M * 3072) * 2 / 1e6,
        "gemm_qkv (EPI_BIAS)": (M * 768 + 2304 * 768 + M * 2304) * 2 / 1e6,
+       "gemm_proj (EPI_BIAS_RESID, K = N)": (M * 768 + 768 * 768 + 2 * M * 768) * 2 / 1e6,   # A + W + residual in + out
+       "gemm_fc2 (EPI_BIAS_RESID, K > N)": (M * 3072 + 768 * 3072 + 2 * M * 768) * 2 / 1e6,
        "attention": (M * 2304 + M * 768) * 2 / 1e6}
 
 
@@ -72,6 +75,16 @@ def main():
                       "lds_conflict_pct": round(extra[3], 1)}
         lines.append(f"{label:32s} | {n:3d} | {read_mb:8.1f} | {write_mb:7.1f} | {ALG.get(label, 0.0):7.1f} | {mfma:5.1f} | {l2:5.1f} | "
                      f"{extra[0]:5.1f} | {extra[1]:5.1f} | {extra[2]:5.1f} | {extra[3]:5.1f}")
+    # the kernels these counters belong to: bench.py drops `roofline.traffic` when the library it runs was built from
+    # other sources (vdr.source_id() = sha256 over csrc/)
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit-deep-radiomics_amd"))
+    try:
+        import vdr
+        res["_source_id"] = vdr.source_id()
+        lines.append(f"# kernel sources: vdr.source_id() = {res['_source_id']}")
+    except Exception as e:  # noqa: BLE001
+        lines.append(f"# kernel sources: unknown ({e})")
     open(out + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump(res, open(out + ".json", "w"), indent=1)
     print("\n".join(lines))

@@ -655,7 +655,9 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
 #undef VDR_GSTAMP
 }
 
-template <int WAVES_M, int WAVES_N, int EPI>
+// TAG: no effect on the code -- a second symbol for the same instantiation, so that a profile separates the two residual
+// GEMMs of a block (TAG 1 = K > N: fc2; TAG 0: the out-projection and everything else)
+template <int WAVES_M, int WAVES_N, int EPI, int TAG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wg = xcd_remap(blockIdx.x, p.nwg);
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4_kernel(Ge
 // argument block and everything loop-invariant derived from them spill (100 SGPRs, 29 VGPRs to scratch) -- the block is
 // re-read per tile through the kernarg pointer made opaque; (ii) hipcc hoists the lane-derived addresses of the body out
 // of the loop (+20 VGPRs at a 128-register budget) -- the body takes an opaque copy of threadIdx.x.
-template <int WAVES_M, int WAVES_N, int EPI>
+template <int WAVES_M, int WAVES_N, int EPI, int TAG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(GemmK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(4))) GemmK* kernarg_ptr;
@@ -726,10 +728,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(G
 }
 
 // PIPE: 3x = ring3 with x LDS slots, 4x = ring3k with x super-slots, 50 = ring4
-template <int WAVES_M, int WAVES_N, int PIPE, int E>
+template <int WAVES_M, int WAVES_N, int PIPE, int E, int TAG = 0>
 static auto launch_pick() -> void (*)(GemmK) {
   if constexpr (PIPE >= 50)
-    return gemm_ring4_kernel<WAVES_M, WAVES_N, E>;
+    return gemm_ring4_kernel<WAVES_M, WAVES_N, E, TAG>;
   else if constexpr (PIPE >= 40)
     return gemm_ring3k_kernel<PIPE - 40, E>;
   else
@@ -740,14 +742,14 @@ static auto launch_pick() -> void (*)(GemmK) {
 inline unsigned long long* g_gemm_stamps = nullptr;  // tools/micro/gemm_stamps.hip
 #endif
 // the persistent form exists for the residual epilogue of ring4 (tuning builds: for every epilogue, variant 2xx)
-template <int WAVES_M, int WAVES_N, int PIPE, int E>
+template <int WAVES_M, int WAVES_N, int PIPE, int E, int TAG = 0>
 static auto launch_pick_persistent() -> void (*)(GemmK) {
 #ifdef VDR_TUNING
-  if constexpr (PIPE >= 50) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E>;
+  if constexpr (PIPE >= 50) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E, TAG>;
 #else
-  if constexpr (PIPE >= 50 && E == EPI_BIAS_RESID) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E>;
+  if constexpr (PIPE >= 50 && E == EPI_BIAS_RESID) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E, TAG>;
 #endif
-  return launch_pick<WAVES_M, WAVES_N, PIPE, E>();
+  return launch_pick<WAVES_M, WAVES_N, PIPE, E, TAG>();
 }
 
 inline int g_gemm_ablation = 0;  // tuning builds only (variant / 100 of vdr_op_linear)
@@ -889,11 +891,12 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     if (pad > 0) lds += (size_t)pad;
   }
 #endif
-#define VDR_LAUNCH(E)                                                                                  \
-  case E: {                                                                                            \
-    auto fn = launch_pick<WAVES_M, WAVES_N, PIPE, E>();                                                \
-    if (persistent && launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>() != fn) {                     \
-      auto pfn = launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E>();                                  \
+#define VDR_LAUNCH(E) VDR_LAUNCH_T(E, 0)
+#define VDR_LAUNCH_T(E, T)                                                                             \
+  case E + 100 * T: {                                                                                  \
+    auto fn = launch_pick<WAVES_M, WAVES_N, PIPE, E, T>();                                             \
+    if (persistent && launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E, T>() != fn) {                  \
+      auto pfn = launch_pick_persistent<WAVES_M, WAVES_N, PIPE, E, T>();                               \
       static int slots_dev[VDR_MAX_DEVICES] = {}; /* workgroups of this instantiation the chip holds at once */ \
       int& slots = slots_dev[dev];                                                                     \
       if (!slots) {                                                                                    \
@@ -923,16 +926,19 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     hipLaunchKernelGGL(fn, grid, block, lds, s, k);                                                    \
     break;                                                                                             \
   }
-  switch (epi) {
+  // (the residual GEMM with K > N -- fc2 -- launches the TAG 1 symbol of the same code: profiles tell it from the out-projection)
+  switch (epi + (PIPE >= 50 && epi == EPI_BIAS_RESID && a.K > a.N ? 100 : 0)) {
     VDR_LAUNCH(EPI_BIAS)
     VDR_LAUNCH(EPI_BIAS_GELU)
     VDR_LAUNCH(EPI_BIAS_RESID)
+    VDR_LAUNCH_T(EPI_BIAS_RESID, 1)
     VDR_LAUNCH(EPI_SWIGLU)
     VDR_LAUNCH(EPI_PATCH)
     default:
       return hipErrorInvalidValue;
   }
 #undef VDR_LAUNCH
+#undef VDR_LAUNCH_T
   return hipGetLastError();
 }
 

@@ -105,3 +105,16 @@ def check(rc: int, handle=None):
     if rc != 0:
         msg = load().vdr_last_error(handle)
         raise VdrError(rc, msg.decode() if msg else "?")
+
+
+def source_id() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources under csrc/ (*.hip, *.h, Makefile, sorted by name): identifies
+    the kernels a committed profile was taken with, independent of when or where libvdr.so was built."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
