@@ -56,6 +56,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
     case 26:
     case 27:
     case 28:
+    case 29:
       return launch_gemm_ring4(a, epilogue, variant, s);
     case 30:
       return launch_gemm_stream(a, epilogue, s);  // stream: persistent 128x256, one 8-wave workgroup per CU, plain W layout

@@ -12,6 +12,8 @@ hipError_t launch_gemm_ring4(const GemmArgs& a, int epilogue, int variant, hipSt
       return launch_cfg<4, 4, 50>(a, epilogue, s);  // ring4: 256x256, 16 waves, 2 x 32 KB + 3 x 16 KB
     case 28:
       return launch_cfg<2, 2, 50>(a, epilogue, s);  // ring4: 128x128, 4 waves, 2 x 16 KB + 3 x 8 KB, 2 WG/CU
+    case 29:
+      return launch_cfg<1, 2, 50>(a, epilogue, s);  // ring4: 64x128, 2 waves, 2 x 8 KB + 3 x 8 KB: launches of a few hundred rows x 768 columns
     default:
       return hipErrorInvalidValue;
   }
