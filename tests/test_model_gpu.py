@@ -279,6 +279,25 @@ def test_layernorm_folding_matches_the_explicit_layernorm_path():
     assert _min_cos(fused.cpu(), ref["tokens"]) >= 0.999
 
 
+def test_stream_gemm_switch_is_bitwise():
+    """vdr_config.stream_gemm = 1 sends the qkv / fc1 linears of launches with >= 1024 tiles to the persistent stream kernel
+    (plain weight layout, LayerNorm-fold statistics and column sums through its LDS constants): the whole forward must be
+    the bits of the ring4 forward -- LayerNorm fold on and off, a batch whose row count is not a multiple of the 128-row
+    tile (the workspace's padding rows are read, never stored), CLS and dense outputs."""
+    import vdr
+    cfg = vo.CONFIGS["vit_base16_224"]
+    w = vo.make_weights(cfg, seed=1)
+    x = vo.make_images(cfg, 100, seed=2).to(torch.bfloat16).cuda()  # 19700 rows: 154 x 9 = 1386 qkv tiles, ragged last tile row
+    for fold in (True, False):
+        base = vdr.load_model("vit_base16_224", weights=w, ln_fold=fold)
+        strm = vdr.load_model("vit_base16_224", weights=w, ln_fold=fold, stream_gemm=True)
+        for mode in (vdr.OUT_CLS, vdr.OUT_DENSE):
+            assert torch.equal(base.engine.forward(x, mode), strm.engine.forward(x, mode)), (fold, mode)
+    # a launch below the threshold stays on ring4 (same bits trivially): the switch must not break small batches
+    small = x[:3].contiguous()
+    assert torch.equal(base.engine.forward(small, vdr.OUT_CLS), strm.engine.forward(small, vdr.OUT_CLS))
+
+
 def _inject_outlier_channels(w, layers, dim, seed, fc1_key):
     """What trained DINOv2-g / SAM checkpoints carry and seeded Gaussian weights do not ("massive activations"): a few
     LayerNorm gains of 30-100x, and residual-stream channels that sit at 10^2..10^3 in every token.  The columns of the

@@ -87,7 +87,7 @@ def test_linear_exact_integers_catches_layout_bugs(ops):
 
 
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("variant", [22, 23, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("variant", [22, 23, 24, 25, 26, 27, 28, 29])
 def test_linear_every_tile_variant_exact(ops, variant, packed):
     """Every tile configuration the library ships (ring3 = LDS ring of 32-deep units, ring3k = K split across two wave
     groups, ring4 = activations staged as 64-deep pieces) on integer data, with the weight in the PyTorch layout and in
@@ -111,13 +111,64 @@ def test_linear_every_tile_variant_exact(ops, variant, packed):
         assert torch.equal(y.float().cpu(), _bf(ref + r).float()), f"variant {variant} resid {(M, N, K)}"
 
 
+def test_linear_stream_variant_exact(ops):
+    """Tile variant 30, the persistent stream GEMM (csrc/gemm_stream.hip: one workgroup per CU, K steps streaming across tile
+    boundaries, the epilogue of a tile inside the next tile's MFMAs, 16-byte stores straight from a permuted accumulator
+    layout): integer data -> bit-exact.  One tile, ragged M (rows past M readable via vdr_op_linear_xrows, never stored:
+    guard rows behind the output stay untouched), several tiles per workgroup, every K-step count class (12 = no rolled
+    loop, 13, 24), bias and erf-GELU epilogues, and the shapes it must refuse."""
+    import vdr
+    from vdr import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID
+    g = torch.Generator().manual_seed(30)
+    for (M, N, K) in [(128, 256, 768), (333, 768, 768), (1000, 512, 832), (130, 256, 1536), (128 * 300 + 5, 256, 768)]:
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-3, 4, (N,), generator=g).float()
+        Mr = (M + 127) // 128 * 128
+        xpad = torch.full((Mr, K), float("nan"), dtype=torch.bfloat16, device="cuda")  # readable, never part of a stored row
+        xpad[:M] = _bf(x).cuda()
+        pad = torch.full((M + 256, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        ref = x @ W.t() + b
+        y = ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS, variant=30, out=pad[:M], x_rows=Mr)
+        torch.cuda.synchronize()
+        assert torch.equal(y.float().cpu(), _bf(ref).float()), f"stream bias {(M, N, K)}"
+        assert bool((pad[M:] == 7.0).all()), f"stream wrote past row M {(M, N, K)}"
+        yg = ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS_GELU, variant=30, x_rows=Mr)
+        assert torch.equal(yg, ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS_GELU, variant=22)), f"stream gelu {(M, N, K)}"
+    x = torch.zeros(256, 768, dtype=torch.bfloat16, device="cuda")
+    W = torch.zeros(256, 768, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(vdr.VdrError):  # ragged M without readable padding rows
+        ops.linear(x[:200], W, None, variant=30)
+    with pytest.raises(vdr.VdrError):  # K < 768: fewer steps than the epilogue schedule needs
+        ops.linear(x[:, :704].contiguous(), W[:, :704].contiguous(), None, variant=30)
+    with pytest.raises(vdr.VdrError):  # N not a multiple of the 256-column tile
+        ops.linear(x, W[:192].contiguous(), None, variant=30)
+    with pytest.raises(vdr.VdrError):  # residual epilogue: ring4 only
+        ops.linear(x, W, None, resid=x[:, :256].contiguous(), epilogue=EPI_BIAS_RESID, variant=30)
+
+
+def test_linear_stream_full_size_equals_ring_bitwise(ops):
+    """At the headline shapes (M = 50432, random data): the stream kernel == ring3, bit for bit, three launches in a row
+    (a race between the LDS ring's stages, the counted waits or the tile hand-over would show as a run-to-run change)."""
+    from vdr import EPI_BIAS, EPI_BIAS_GELU
+    g = torch.Generator().manual_seed(12)
+    M = 50432
+    for (N, K, epi) in [(2304, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (768, 3072, EPI_BIAS)]:
+        x = _bf(torch.randn(M, K, generator=g)).cuda()
+        W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        a = ops.linear(x, W, b, epilogue=epi, variant=22)
+        for rep in range(3):
+            assert torch.equal(a, ops.linear(x, W, b, epilogue=epi, variant=30)), (N, K, rep)
+
+
 def test_linear_rejects_unknown_and_ablation_variants(ops):
     """The variant argument of the C ABI selects a shipped tile configuration; diagnostic encodings (>= 100, tuning
     builds) and retired numbers are an error, never a silent garbage result."""
     import vdr
     x = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
     tuning = bool(vdr.load().vdr_tuning_build())  # a tools/ build accepts the ablation encodings
-    for bad in (5, 21, 29) + (() if tuning else (122, 822)):
+    for bad in (5, 21, 31) + (() if tuning else (122, 822)):
         with pytest.raises(vdr.VdrError):
             ops.linear(x, x, None, variant=bad)
 
