@@ -96,6 +96,31 @@ def cpu_baseline(cfg_name, seconds_target=12.0, max_threads=64):
                       f"{os.cpu_count()} logical CPUs visible"}
 
 
+def cpu_baseline_sam(seconds_target=12.0, max_threads=64):
+    """The reference's default backbone on the host cores: one 1024^2 slice at a time through the SAM ViT-B image encoder
+    restated in oracle/sam_oracle.py (12 blocks, window 14 + 4 global blocks, conv neck), fp32 -- what
+    tfds_dense_descriptor.py:271-281 does per slice on a machine without a GPU.  Bounded sample."""
+    from oracle import sam_oracle as so
+    cfg = so.SAM_VIT_B
+    cores = min(usable_cores(), max_threads)
+    torch.set_num_threads(cores)
+    w = so.make_weights(cfg, seed=1)
+    x = so.make_images(cfg, 1, seed=0)
+    t0 = time.perf_counter()
+    so.sam_forward(cfg, w, x)  # warm-up
+    warm = time.perf_counter() - t0
+    runs, t0 = 0, time.perf_counter()
+    while True:
+        so.sam_forward(cfg, w, x)
+        runs += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or runs >= 50 or dt + warm > 2.5 * seconds_target:
+            break
+    return {"value": round(runs / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{runs} slices of 1024^2 through oracle/sam_oracle.sam_forward (SAM ViT-B encoder, fp32), one per call, {dt:.1f} s wall, "
+                      f"{os.cpu_count()} logical CPUs visible"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,8 +414,8 @@ def main():
                "gather": gather,
                "TFLOPs_per_s": round(flops_img * total * a.steps / dt / 1e12, 1),
                "roofline": roof, "kernels": kern, "two_stream": two, "full_last_block": full}
-        if not a.no_cpu_baseline and world == 1 and not sam:
-            out["cpu_baseline"] = cpu_baseline(a.model)
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_sam() if sam else cpu_baseline(a.model)
         print(json.dumps(out), flush=True)
     if launched:
         dist.barrier()

@@ -117,6 +117,9 @@ typedef struct {
                       /* row-wise and x[:, 0] is all `model(x) -> (logits, cls)` (models_archs.py:24-29) returns; the   */
                       /* features are bitwise those of the full block.  1: every row (A/B, tests, bench.py              */
                       /* --full-last-block).  Other out_modes and post-LN models always run every row.                  */
+  int32_t patch_fusion; /* 1: p = 14 and fp32-pixel patch embeddings run patchify + GEMM + epilogue in ONE launch           */
+                      /* (csrc/patch_fused.hip; same bits; measured slower than the two launches: see that file);        */
+                      /* 0 (default): im2col + GEMM                                                                      */
   int32_t stream_gemm; /* 1: the qkv and fc1 (GELU) linears of launches with >= 1024 tiles (K >= 768, N % 256 == 0) run on  */
                       /* the persistent "stream" kernel (csrc/gemm_stream.hip: one workgroup per CU, K steps streaming      */
                       /* across tile boundaries, epilogue of a tile inside the next tile's MFMAs) instead of the ring4     */
@@ -341,6 +344,13 @@ int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float
 int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const float* bias,
                        const float* pos, void* col, void* y, int batch, int C, int img, int p, int D,
                        int row_stride, int row_offset, void* stream);
+/* The same operator in ONE launch (csrc/patch_fused.hip): the im2col rows of 32 neighbouring patches are built in LDS
+ * and multiplied there -- no `col` scratch.  What vdr_forward runs for p = 14 and for fp32 pixels (the reference's input
+ * dtype, tfds_dense_descriptor.py:47) when vdr_config.patch_fusion is set.  Even p, img % p == 0, images 8-byte
+ * aligned, D % 8 == 0; y bf16 or fp32 (out_dtype) rows of D.  Results are bitwise those of vdr_op_patch_embed. */
+int vdr_op_patch_embed_fused(const void* images, int in_dtype, const void* W, const float* bias, const float* pos,
+                             void* y, int out_dtype, int batch, int C, int img, int p, int D, int row_stride,
+                             int row_offset, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 

@@ -298,6 +298,30 @@ def test_stream_gemm_switch_is_bitwise():
     assert torch.equal(base.engine.forward(small, vdr.OUT_CLS), strm.engine.forward(small, vdr.OUT_CLS))
 
 
+@pytest.mark.parametrize("name,dt", [("p14_d192", torch.float32), ("p14_d192", torch.bfloat16), ("dinov2_swiglu_ls", torch.float32),
+                                     ("p16_d128", torch.float32)])
+def test_patch_fusion_switch_is_bitwise(name, dt):
+    """vdr_config.patch_fusion: the one-launch patch embedding (p = 14, fp32 pixels) against im2col + GEMM inside the whole
+    forward -- tokens, LayerNorm partials for block 0's folded norm1 and everything downstream are the same bits."""
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=51, scale=0.05)
+    x = vo.make_images(cfg, 5, seed=52).to(dt).cuda()
+
+    def eng(fusion):
+        vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
+                           mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
+                           has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps, patch_fusion=fusion)
+        e = vdr.Engine(vc)
+        e.load_weights(w)
+        return e
+
+    a, b = eng(True), eng(False)
+    for mode in (vdr.OUT_PATCH_EMBED, vdr.OUT_TOKENS, vdr.OUT_CLS):
+        assert torch.equal(a.forward(x, mode), b.forward(x, mode)), (name, dt, mode)
+    assert torch.equal(a.forward(x, vdr.OUT_PATCH_EMBED, torch.bfloat16), b.forward(x, vdr.OUT_PATCH_EMBED, torch.bfloat16))
+
+
 def _inject_outlier_channels(w, layers, dim, seed, fc1_key):
     """What trained DINOv2-g / SAM checkpoints carry and seeded Gaussian weights do not ("massive activations"): a few
     LayerNorm gains of 30-100x, and residual-stream channels that sit at 10^2..10^3 in every token.  The columns of the

@@ -417,6 +417,34 @@ def test_patch_embed_gathered_from_images_exact(ops, img, p, D, B):
     assert torch.equal(y2[:, 1:].reshape(B * n, D), _bf(ref + pos[1:].repeat(B, 1)).float())
 
 
+@pytest.mark.parametrize("img,p,D,B,dt", [(224, 14, 384, 3, torch.float32), (224, 14, 384, 3, torch.bfloat16),
+                                           (896, 14, 384, 2, torch.float32), (336, 14, 1024, 2, torch.bfloat16),
+                                           (518, 14, 200, 1, torch.float32), (256, 16, 768, 2, torch.float32),
+                                           (64, 8, 1536, 5, torch.float32)])
+def test_patch_embed_fused_equals_two_launches(ops, img, p, D, B, dt):
+    """The one-launch patch embedding (csrc/patch_fused.hip: im2col rows built and multiplied in LDS) against im2col + GEMM:
+    bitwise equal -- same products in the same order, same epilogue arithmetic -- for p = 14 and fp32 pixels, grids of 16,
+    24, 37 (ragged last workgroup of a patch row) and 64 patches per row, D with and without whole 64 / 512-column passes,
+    a cls offset in the output rows and a position table; the fp32 output rounds to the bf16 output."""
+    g = torch.Generator().manual_seed(img + p + D)
+    x = torch.rand(B, 3, img, img, generator=g).to(dt).cuda()
+    W = (torch.randn(D, 3, p, p, generator=g) * 0.05)
+    b = torch.randn(D, generator=g).cuda()
+    n = (img // p) ** 2
+    pos = torch.randn(n + 1, D, generator=g).cuda()
+    two = ops.patch_embed(x, W.cuda(), b, p, pos=pos, row_stride=n + 1, row_offset=1)
+    one = ops.patch_embed_fused(x, W.cuda(), b, p, pos=pos, row_stride=n + 1, row_offset=1)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"fused patch embed differs from im2col + GEMM {(img, p, D, B, dt)}"
+    assert bool((one.view(B, n + 1, D)[:, 0] == 0).all())  # the cls rows are not this operator's
+    f32 = ops.patch_embed_fused(x, W.cuda(), b, p, pos=None, out_dtype=torch.float32)
+    assert f32.dtype == torch.float32 and torch.equal(f32.to(torch.bfloat16), ops.patch_embed(x, W.cuda(), b, p))
+    # against the convolution itself (bf16-rounded operands, fp32 accumulate): one bf16 rounding of the output
+    ref = torch.nn.functional.conv2d(x.float().to(torch.bfloat16).float(), W.cuda().to(torch.bfloat16).float(), b, stride=p)
+    ref = ref.flatten(2).transpose(1, 2).reshape(B * n, D)
+    _assert_close(f32, ref, 1e-5, 2e-4 * math.sqrt(3 * p * p / 588), "fused patch embed vs conv2d")
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_patch_embed_p14_exact(ops, dt):
     """p = 14 (DINOv2 / ViT-L/14 / ViT-g/14) goes through the LDS im2col (coalesced pixel pairs scattered into [patch][K]

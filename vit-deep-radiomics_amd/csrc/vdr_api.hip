@@ -1362,11 +1362,24 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     // is an LDS-DMA: it cannot convert) and p = 14 (runs of 14 pixels are not 16-byte chunks) go through im2col.
     const int pvar = gemm_variant_for(VDR_K_GEMM_PATCH, (int64_t)mb * n, D);
     const bool fused_patch = patch_gather_ok(in_dtype, c.patch, pvar, img);
+    const bool pe_only = out_mode == VDR_OUT_PATCH_EMBED;
+    // vdr_config.patch_fusion: what the in-loader gather does not take -- p = 14, fp32 pixels (what the reference feeds) --
+    // runs the patchify, the GEMM and its epilogue in ONE launch (patch_fused.hip: same bits, measured slower; off by default)
+    const bool one_launch = !fused_patch && c.patch_fusion && patch_fused_ok(img, in_dtype == VDR_BF16, c.img, c.patch, m->Kp, D);
+    if (one_launch) {
+      void* dst = pe_only ? (void*)((char*)out + (size_t)b0 * n * D * (out_dtype == VDR_BF16 ? 2 : 4)) : (void*)w.x;
+      const int f32 = pe_only && out_dtype != VDR_BF16;
+      const RowMap om = pe_only ? RowMap{n, n, 0} : RowMap{n, ntok, ncls};
+      Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * mb * n * D * c.in_chans * c.patch * c.patch,
+               (double)mb * img_elems * in_es + 2.0 * D * m->Kp + (double)mb * n * D * (f32 ? 4 : 2));
+      VDR_TRY(launch_patch_fused(img, in_dtype == VDR_BF16, m->w_patch, m->b_patch, pe_only ? nullptr : m->pos, dst, f32,
+                                 (m->ln_fuse && !pe_only) ? w.part : nullptr, w.Mp, mb, c.in_chans, c.img, c.patch, m->Kp, D, om, s),
+              "patch embed");
+    } else {
     if (!fused_patch) {
       Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)mb * img_elems * in_es + 2.0 * mb * n * m->Kp);
       VDR_TRY(launch_im2col(img, in_dtype == VDR_BF16, w.u, mb, c.in_chans, c.img, c.patch, m->Kp, s), "im2col");
     }
-    const bool pe_only = out_mode == VDR_OUT_PATCH_EMBED;
     {
       GemmArgs g{};
       g.A = fused_patch ? (const void*)img : (const void*)w.u;
@@ -1402,6 +1415,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
       VDR_TRY(launch_gemm_w(m, g, EPI_PATCH, pvar, s), "patch gemm");
+    }
     }
     if (pe_only) continue;
     if (c.window > 0) {
@@ -1748,6 +1762,22 @@ int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float
   OP_TRY(launch_relpos_pack(rel_pos_h, rel_pos_w, table, S, (hipStream_t)stream), "relpos_pack");
   OP_TRY(relpos_products(qkv, table, rel, tokens, S, heads, (hipStream_t)stream), "relpos");
   OP_TRY(launch_attention_relpos(qkv, rel, out, batch, S, heads, (hipStream_t)stream), "attention_relpos");
+  return VDR_OK;
+}
+
+int vdr_op_patch_embed_fused(const void* images, int in_dtype, const void* W, const float* bias, const float* pos, void* y,
+                             int out_dtype, int batch, int C, int img, int p, int D, int row_stride, int row_offset, void* stream) {
+  if (!images || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
+  if (p <= 0 || img % p) return fail(nullptr, VDR_ERR_INVALID, "img must be a multiple of p");
+  if ((in_dtype != VDR_F32 && in_dtype != VDR_BF16) || (out_dtype != VDR_F32 && out_dtype != VDR_BF16))
+    return fail(nullptr, VDR_ERR_INVALID, "dtype");
+  int rc = check_device(nullptr);
+  if (rc) return rc;
+  const int g = img / p, n = g * g, Kp = round_up(C * p * p, 64);
+  if (!patch_fused_ok(images, in_dtype == VDR_BF16, img, p, Kp, D))
+    return fail(nullptr, VDR_ERR_UNSUPPORTED, "patch_embed_fused: even p, 8-byte aligned images, D % 8 == 0, 32 (2 Kp + 32) <= 80 KB required");
+  OP_TRY(launch_patch_fused(images, in_dtype == VDR_BF16, W, bias, pos, y, out_dtype == VDR_F32, nullptr, 0, batch, C, img, p, Kp, D,
+                            RowMap{n, row_stride, row_offset}, (hipStream_t)stream), "patch_embed_fused");
   return VDR_OK;
 }
 

@@ -171,6 +171,13 @@ hipError_t launch_im2col3(const void* y, void* col, int batch, int g, int C, hip
 hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,
                          int Kp, hipStream_t s);
 
+// patchify + GEMM + epilogue in one launch (patch_fused.hip): even patch sides, fp32 or bf16 pixels; W [D][Kp] in the plain
+// layout; out = bf16 token rows (optionally + LayerNorm partials) or fp32 rows.  Bitwise equal to launch_im2col + EPI_PATCH GEMM
+bool patch_fused_ok(const void* images, int in_bf16, int img, int p, int Kp, int D);
+hipError_t launch_patch_fused(const void* images, int in_bf16, const void* W, const float* bias, const float* pos, void* out,
+                              int out_f32, float* ln_part, int64_t part_stride, int batch, int C, int img, int p, int Kp, int D,
+                              RowMap omap, hipStream_t s);
+
 // x[b*row_stride + 0][:] = cls + pos[0]  (bf16 out)
 hipError_t launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int64_t row_stride,
                            int D, hipStream_t s);

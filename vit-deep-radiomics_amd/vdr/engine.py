@@ -37,6 +37,7 @@ class VdrConfig:
     ln_fold: bool = True       # pre-LN image models: LayerNorm folded into the qkv / fc1 GEMMs (False: explicit kernel)
     full_last_block: bool = False  # CLS output: True keeps every row of the last block (default: its CLS rows only,
                                # the same features bit for bit; see vdr_config.full_last_block)
+    patch_fusion: bool = False  # True: p = 14 / fp32-pixel patch embedding in one launch (same bits; measured slower)
     stream_gemm: bool = False  # qkv / fc1 of large launches on the persistent stream kernel (vdr_config.stream_gemm; same bits)
 
     @property
@@ -61,6 +62,7 @@ class VdrConfig:
         c.no_ln_fold = int(not self.ln_fold)
         c.full_last_block = int(self.full_last_block)
         c.stream_gemm = int(self.stream_gemm)
+        c.patch_fusion = int(self.patch_fusion)
         return c
 
 

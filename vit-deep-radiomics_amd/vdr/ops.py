@@ -163,6 +163,26 @@ def patch_embed(images, weight, bias, p, pos=None, row_stride=None, row_offset=0
     return out
 
 
+def patch_embed_fused(images, weight, bias, p, pos=None, row_stride=None, row_offset=0, out_dtype=torch.bfloat16):
+    """patch_embed in one launch (vdr_op_patch_embed_fused): no col scratch; bf16 or fp32 rows out."""
+    lib = L.load()
+    B, Cc, H, _ = images.shape
+    D = weight.shape[0]
+    g = H // p
+    n = g * g
+    K = Cc * p * p
+    Kp = (K + 63) // 64 * 64
+    Wp = torch.zeros((D, Kp), dtype=torch.bfloat16, device=images.device)
+    Wp[:, :K] = weight.reshape(D, K).to(torch.bfloat16)
+    row_stride = n if row_stride is None else row_stride
+    out = torch.zeros((B * row_stride, D), dtype=out_dtype, device=images.device)
+    images = images.contiguous()
+    L.check(lib.vdr_op_patch_embed_fused(images.data_ptr(), 1 if images.dtype == torch.bfloat16 else 0, Wp.data_ptr(), _p(bias), _p(pos),
+                                         out.data_ptr(), 1 if out_dtype == torch.bfloat16 else 0, B, Cc, H, p, D, row_stride, row_offset,
+                                         _s(images)))
+    return out
+
+
 def attention_relpos(qkv: torch.Tensor, rel_pos_h: torch.Tensor, rel_pos_w: torch.Tensor, batch: int, S: int, heads: int):
     """SAM attention with decomposed relative position bias over `batch` windows/grids of S x S tokens."""
     lib = L.load()
