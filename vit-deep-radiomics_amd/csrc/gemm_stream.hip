@@ -424,6 +424,14 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(StreamK p) {
     constexpr int SI = decltype(si_tag)::value, MODE = decltype(mode_tag)::value, NV = decltype(nv_tag)::value;
     const int nslot = slot == 2 ? 0 : slot + 1;
     half_addr(slot, 1);
+#if defined(ST_ABL_XIDLE)
+    const bool do_mma = wave >= 4;  // diagnostic: waves 0-3 only synchronise -> what waves 4-7 do alone on their SIMDs
+#elif defined(ST_ABL_YIDLE)
+    const bool do_mma = wave < 4;
+#else
+    constexpr bool do_mma = true;
+#endif
+    if (do_mma)
     static_for<16>([&](auto ls_tag) {
       constexpr int LS = decltype(ls_tag)::value, i = LS >> 2, j = LS & 3;
       if constexpr (MODE == 1) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm_stream_kernel(StreamK p) {
 #endif
     half_addr(nslot, 0);
     // Second half: the same 16 slots for every wave.
+    if (do_mma)
     static_for<16>([&](auto ls_tag) {
       constexpr int LS = decltype(ls_tag)::value, i = LS >> 2, j = LS & 3;
       if constexpr (MODE == 2) prev[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[j][i], 0, 0, 0);
