@@ -4,7 +4,11 @@
 // shipped library has none).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize -DVDR_STREAM_STAMPS -I vit-deep-radiomics_amd/csrc tools/micro/stream_stamps.hip -o tools/micro/stream_stamps
 //   tools/micro/stream_stamps [shape = fc1 | qkv | widek]
+#ifdef ST_MFMA32
+#include "gemm_stream_mfma32.hip"  // the 32x32x16 experiment (this directory)
+#else
 #include "gemm_stream.hip"
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
