@@ -193,11 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     for (int t = 0; t < NT; ++t) {
       if (kc0 + t * 32 + 32 > len) mask_keys(s[t], kc0 + t * 32, hh, len);
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    float mx = row_max_tiles<NT>(s);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     if (rescale) {
@@ -210,19 +206,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
     }
     m_run = m_new;
     const float mb = m_new * sc;
-    float lsum = 0.0f;
+    f32x2 lsum2 = {0.0f, 0.0f};  // fp32 row sum, (even, odd) elements (same order in the persistent kernel: bitwise equal)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         if (kc0 + t * 32 + s2 * 16 >= len) continue;  // fully masked slice (wave-uniform): P = 0, nothing to add
         bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
-          lsum += pv;  // fp32 row sum (same order in the persistent kernel: results are bitwise equal)
-          pf[j] = (bf16_t)pv;
-        }
+        softmax_slice8(s[t], s2, sc, -mb, lsum2, pf);
 #pragma unroll
         for (int nd = 0; nd < 2; ++nd) {
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sVtr + (t * 32 + s2 * 16) * 128 + vch[nd]));
@@ -238,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnK p) {
         __builtin_amdgcn_sched_barrier(0);  // keep the exp/cvt of later key slices from being hoisted (VGPR cap)
       }
     }
-    l_run += lsum;
+    l_run += lsum2[0] + lsum2[1];
   };
 
   auto store = [&](int qt) {
@@ -446,18 +437,14 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
       for (int t = 0; t < NT; ++t)
         if (t * 32 + 32 > p.seq) mask_keys(s[t], t * 32, hh, p.seq);
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    float mx = row_max_tiles<NT>(s);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mb = mx * sc;
 #ifdef VDR_ATTN_STAMPS
     asm volatile("" : "+v"(mx));
 #endif
     VDR_STAMP(3);
-    float lsum = 0.0f;
+    f32x2 lsum2 = {0.0f, 0.0f};
     f32x16 o[2];
 #pragma unroll
     for (int nd = 0; nd < 2; ++nd)
@@ -479,12 +466,7 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
     };
     auto make_p = [&](int it, int set) {
       const int t = it >> 1, s2 = it & 1;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], sc, -mb));
-        lsum += pv;
-        pf[set][j] = (bf16_t)pv;
-      }
+      softmax_slice8(s[t], s2, sc, -mb, lsum2, pf[set]);
     };
     read_v(0);
     make_p(0, 0);
@@ -508,6 +490,7 @@ __global__ __launch_bounds__(LOADER ? 512 : 448, 2) void attn_persist_kernel(Att
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    const float lsum = lsum2[0] + lsum2[1];
     const float l = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / l;
     const int q = qt * 32 + l31;

@@ -264,18 +264,13 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
     crow[1] = MULTI ? fmaf(relh[1], SC, -mb) : -mb;
     // (The row sum through the matrix pipe instead -- one more MFMA per 16-key slice with an all-ones A operand, 8 issue
     // cycles against 32 for the 8 adds it replaces -- measured the same within noise: 7.16 vs 7.34 ms per MedSAM step.)
-    float lsum = 0.0f;
+    f32x2 lsum2 = {0.0f, 0.0f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = fast_exp2(fmaf(s[t][8 * s2 + j], SC, crow[MULTI ? t >> 1 : 0]));
-          lsum += pv;
-          pf[j] = (bf16_t)pv;
-        }
+        softmax_slice8(s[t], s2, SC, crow[MULTI ? t >> 1 : 0], lsum2, pf);  // packed pairs: vdr_dev.h
 #pragma unroll
         for (int nd = 0; nd < 2; ++nd) {
           const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sVtr + (t * 32 + s2 * 16) * 128 + vch[nd]));
@@ -291,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_relpos_kernel(AttnRK p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    l_run += lsum;
+    l_run += lsum2[0] + lsum2[1];
   };
 
   auto store = [&](int qt) {

@@ -7,6 +7,7 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -72,6 +73,38 @@ VDR_DEV float gelu_erf(float x) {
   q = fmaf(q, a, -1.150403490e+00f);
   q = fmaf(q, a, -1.000050145e+00f);
   return relu - a * fast_exp2(q);
+}
+
+// One 16-key slice of a softmax row held in the S^T accumulator layout: P = 2^(s * sc + nmb) for the 8 scores of this
+// lane, their sum added to `lsum2`, P rounded to bf16 as the B operand of O^T += V^T . P^T.  Written on PAIRS of
+// neighbouring accumulator registers so that the scale-and-shift and the row sum are one packed instruction per pair
+// (v_pk_fma_f32, v_pk_add_f32: two lanes of fp32 per issue slot): 5 vector instructions per pair instead of 7, and the
+// attention kernels are bound by vector issue.  The row sum is kept as (even elements, odd elements) and folded once at
+// the end of the row; every attention kernel sums in this order, so their outputs stay bitwise equal to each other.
+VDR_DEV void softmax_slice8(const f32x16& st, int s2, float sc, float nmb, f32x2& lsum2, bf16x8& pf) {
+  const f32x2 sc2 = {sc, sc}, nmb2 = {nmb, nmb};
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    f32x2 x = {st[8 * s2 + j], st[8 * s2 + j + 1]};
+    x = __builtin_elementwise_fma(x, sc2, nmb2);
+    f32x2 pv;
+    pv[0] = fast_exp2(x[0]);
+    pv[1] = fast_exp2(x[1]);
+    lsum2 += pv;
+    pf[j] = (bf16_t)pv[0];
+    pf[j + 1] = (bf16_t)pv[1];
+  }
+}
+
+// row maximum of NT accumulator tiles as four independent chains (a single chain of v_max3 is 8 NT dependent instructions)
+template <int NT>
+VDR_DEV float row_max_tiles(const f32x16 (&s)[NT]) {
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m[(e >> 1) & 3] = fmaxf(m[(e >> 1) & 3], s[t][e]);
+  return fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
 }
 
 VDR_DEV float silu(float x) { return x * fast_rcp(1.0f + fast_exp2(-x * 1.44269504088896341f)); }
