@@ -206,3 +206,23 @@ def test_device_gelu_polynomial_matches_erf_gelu():
     err = np.abs(got - ref)
     assert (err <= 1e-4 * np.abs(ref) + 3e-7).all(), float((err / (np.abs(ref) + 3e-3)).max())
     assert err.max() < 8e-6
+
+
+def test_source_id_names_the_kernel_sources(tmp_path, monkeypatch):
+    """vdr.source_id() is what ties a committed PMC profile to the kernels it was taken with (bench.py drops
+    `roofline.traffic` when the ids differ): 16 hex digits, the same on every call, different as soon as one byte of a
+    file under csrc/ differs."""
+    import shutil
+    import vdr
+    from vdr import _lib
+    sid = vdr.source_id()
+    assert len(sid) == 16 and int(sid, 16) >= 0 and vdr.source_id() == sid
+    pkg = os.path.dirname(os.path.dirname(os.path.abspath(_lib.__file__)))
+    clone = tmp_path / "pkg"
+    (clone / "vdr").mkdir(parents=True)
+    shutil.copytree(os.path.join(pkg, "csrc"), clone / "csrc", ignore=shutil.ignore_patterns("build*"))
+    monkeypatch.setattr(_lib, "__file__", str(clone / "vdr" / "_lib.py"))
+    assert _lib.source_id() == sid
+    with open(clone / "csrc" / "vdr_dev.h", "a") as f:
+        f.write("\n")
+    assert _lib.source_id() != sid
