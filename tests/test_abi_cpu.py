@@ -73,3 +73,24 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("oracle's", ""), f"{f} mentions the oracle"
+
+
+def test_no_wide_buffer_store_is_followed_by_a_write_of_its_data():
+    """gfx950 hazard found in round 3 (tools/hazard_scan.py, tools/micro/gemm_ring4d_experiment.hip): a buffer_store_dwordx4
+    with an SGPR soffset followed at once by a VALU write of one of its data registers can store the new value, and hipcc
+    inserts no wait state for that form.  The kernels that use such stores (everything that includes gemm_epi.h) are
+    compiled to ISA here and scanned: none may contain the pattern."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(ROOT, "tools", "hazard_scan.py"))
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    srcs = [f for f in sorted(glob.glob(os.path.join(hs.CSRC, "*.hip")))
+            if "raw_buffer_store" in open(f).read() or "gemm_kernels.h" in open(f).read()]
+    assert srcs
+    total = 0
+    for s in hs.compile_isa(srcs, jobs=4):
+        n, hits = hs.scan(s, 4)
+        total += n
+        assert not hits, hits[:3]
+    assert total > 0  # the scan saw the stores it is about

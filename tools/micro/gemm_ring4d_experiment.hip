@@ -1,17 +1,24 @@
 // EXPERIMENT, not built into the library (round 3).  To try it again: copy to csrc/, add it to the Makefile's SRCS, give
 // launch_cfg a PIPE == 51 hook that calls launch_ring4d before its launch switch, and map a variant number to
 // launch_cfg<2, 4, 51>.
-// Result on one MI355X, M = 50432, interleaved with ring4 (variant 26, packed weights), draw through atomicAdd:
-//     qkv (N 2304, K 768)  ring4 171.1 us   this 178.3        fc1 (N 3072, K 768, erf-GELU)  258.0 / 252.6
-//     N 768, K 3072        228.1 / 229.1
-// i.e. hiding the prologue behind the epilogue is paid back by the second barrier, the per-tile address arithmetic
-// and 16-row x 64-B store instructions in place of whole 128-B lines (the CU's address path is what both kernels wait on:
-// DESIGN.md 4.7).  Bitwise equal to ring4 on qkv / fc1 / the integer cases, but NOT on the K = 3072 launch: accumulator
-// elements [j = 2][i = 2][0..1] of lanes 12-15 (mod 16) of one wave per ~1 % of the tiles come out as raw operand bits --
-// unexplained, which is why this is parked and not shipped.  Two more findings worth keeping:
+// Result on one MI355X, M = 50432, interleaved with ring4 (variant 26, packed weights), draw through atomicAdd, bitwise
+// equal to ring4 on every case of tools/stream_check.py:
+//     qkv (N 2304, K 768)  ring4 176.4 us   this 180.3        fc1 (N 3072, K 768, erf-GELU)  254.4 / 257.7
+//     N 768, K 3072        222.2 / 223.1
+// i.e. hiding the prologue behind the epilogue is paid back by the second barrier, the per-tile address arithmetic, 16-row
+// x 64-B store instructions in place of whole 128-B lines (the CU's address path is what both kernels wait on: DESIGN.md
+// 4.7) and thread 0's wave sitting out its own fill behind the draw (below).  Findings worth keeping:
+//   * A HARDWARE HAZARD hipcc (ROCm 7.2) does not cover: `buffer_store_dwordx4 v[a:a+3], voff, rsrc, sN offen` -- an SGPR
+//     soffset -- followed IMMEDIATELY by a VALU write of v[a] can store the NEW value of that register (seen in lanes 12-15 of
+//     every 16, in the second wave of a SIMD, in ~1 % of the tiles of the K = 3072 launch: the first dword of the 16-byte
+//     store held the next block's unconverted fp32 sum).  LLVM's hazard recognizer inserts the wait state only when the
+//     soffset is NOT a register.  Two wait states behind the store, tied to its data registers so that the scheduler cannot
+//     move the write in front of them (R4D_STORE_NOP below), make the kernel bit-exact; tools/hazard_scan.py looks for the
+//     pattern in the library's ISA (none: the shipped stores with an SGPR soffset are followed by other stores or the end).
 //   * with the draw as an opaque `global_atomic_add v127 ... sc0` (v127 kept out of hipcc's hands by amdgpu_num_vgpr(127))
-//     the kernel raised a memory access fault on its first multi-tile launch; with atomicAdd it does not.  The builtin
-//     costs thread 0's wave a vmcnt(0) right behind the draw (hipcc's atomic optimizer reads the result back at once);
+//     the kernel raises a memory access fault on its first multi-tile launch, with or without wait states behind the
+//     instruction; with atomicAdd it does not.  The builtin costs thread 0's wave a vmcnt(0) right behind the draw (hipcc's
+//     atomic optimizer reads the result back at once), i.e. that wave's fill is not overlapped;
 //   * the launcher once asked for 80 KB + 16 B of LDS: one workgroup per CU instead of two, 215 / 306 / 260 us.
 //
 // ring4d: the ring4 main loop (gemm_kernels.h: 128 x 256 tile, 8 waves, two workgroups per CU) as PERSISTENT workgroups
@@ -40,6 +47,7 @@
 //     ahead.  The draw that returns the last value of its XCD resets the counter: no memset between launches.  (Static
 //     striding lost 13 % on qkv in round 2: the hardware dispatcher's back-fill is a dynamic queue, and this is one.)
 // Same products in the same order and the same epilogue formulas as ring4: outputs are bitwise equal (tests/test_ops_gpu.py).
+#define R4D_STORE_NOP 1
 #define R4D_BUILTIN_DRAW 1  // (the asm draw faults: see the header)
 #include <mutex>
 
@@ -346,6 +354,10 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(127))) void 
           }
           if (p.nt_store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, (uint32_t)(i * 16) * ldc2, 2 /* nt */);
           else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rc, voff, (uint32_t)(i * 16) * ldc2, 0);
+#ifdef R4D_STORE_NOP
+          asm volatile("s_nop 1" : "+v"(o) : : "memory");  // hazard test: VALU write of the store's first data register right behind a store with an SGPR soffset
+#endif
+
         }
         if (jp == 0) __builtin_amdgcn_sched_barrier(0);  // (the second pair's arithmetic stays behind the first pair's stores)
       }

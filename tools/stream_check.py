@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--skip-timing", action="store_true")
+    ap.add_argument("--variant", type=int, default=30, help="30 = stream kernel (plain weights); other numbers: packed weights")
     a = ap.parse_args()
     dev = "cuda"
     g = torch.Generator().manual_seed(3)
@@ -33,7 +34,10 @@ def main():
         ref = ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=22)
         pad = torch.full((M + 256, N), 7.0, device=dev, dtype=torch.bfloat16)
         out = pad[:M]
-        ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=30, out=out, x_rows=Mr)
+        if a.variant == 30:
+            ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=30, out=out, x_rows=Mr)
+        else:
+            ops.linear(xd, Wd, bd, epilogue=vdr.EPI_BIAS, variant=a.variant, out=out)
         torch.cuda.synchronize()
         same = torch.equal(out, ref)
         guard = bool((pad[M:] == 7.0).all())
@@ -56,7 +60,10 @@ def main():
         ops.linear(x, Wp, b, epilogue=epi, variant=26, out=o26, packed=True)
         for rep in range(3):
             o30.zero_()
-            ops.linear(x, W, b, epilogue=epi, variant=30, out=o30)
+            if a.variant == 30:
+                ops.linear(x, W, b, epilogue=epi, variant=30, out=o30)
+            else:
+                ops.linear(x, Wp, b, epilogue=epi, variant=a.variant, out=o30, packed=True)
             torch.cuda.synchronize()
             same = torch.equal(o26, o30)
             if not same:
@@ -67,7 +74,10 @@ def main():
             ok &= same
         print(f"rand {name} M{M} N{N} K{K}: equal={same}", flush=True)
         cases.append((name, N, K, 26, lambda x=x, Wp=Wp, b=b, epi=epi, o=o26: ops.linear(x, Wp, b, epilogue=epi, variant=26, out=o, packed=True)))
-        cases.append((name, N, K, 30, lambda x=x, W=W, b=b, epi=epi, o=o30: ops.linear(x, W, b, epilogue=epi, variant=30, out=o)))
+        if a.variant == 30:
+            cases.append((name, N, K, 30, lambda x=x, W=W, b=b, epi=epi, o=o30: ops.linear(x, W, b, epilogue=epi, variant=30, out=o)))
+        else:
+            cases.append((name, N, K, a.variant, lambda x=x, Wp=Wp, b=b, epi=epi, o=o30, v=a.variant: ops.linear(x, Wp, b, epilogue=epi, variant=v, out=o, packed=True)))
     print("ALL EQUAL" if ok else "FAILED", flush=True)
     if a.skip_timing:
         return 0 if ok else 1
