@@ -1,13 +1,16 @@
 // EXPERIMENT, not built into the library (round 3).  To try it again: copy to csrc/, add it to the Makefile's SRCS, give
 // launch_cfg a PIPE == 51 hook that calls launch_ring4d before its launch switch, and map a variant number to
 // launch_cfg<2, 4, 51>.
-// Result on one MI355X, M = 50432, interleaved with ring4 (variant 26, packed weights), draw through atomicAdd, bitwise
-// equal to ring4 on every case of tools/stream_check.py:
-//     qkv (N 2304, K 768)  ring4 176.4 us   this 180.3        fc1 (N 3072, K 768, erf-GELU)  254.4 / 257.7
-//     N 768, K 3072        222.2 / 223.1
-// i.e. hiding the prologue behind the epilogue is paid back by the second barrier, the per-tile address arithmetic, 16-row
-// x 64-B store instructions in place of whole 128-B lines (the CU's address path is what both kernels wait on: DESIGN.md
-// 4.7) and thread 0's wave sitting out its own fill behind the draw (below).  Findings worth keeping:
+// Result on one MI355X, M = 50432, interleaved with ring4 (variant 26, packed weights), bitwise equal to ring4 on every case of
+// tools/stream_check.py and, as the fc1 of the whole forward, on tools/ab_stream_forward.py (LayerNorm fold on and off):
+//     every tile drawn (first form):   qkv 176.4 -> 180.3 us    fc1 (erf-GELU) 254.4 -> 257.7    N 768 / K 3072 222.2 -> 223.1
+//     static head + dynamic tail:      qkv 164.8 -> 171.7       fc1 245.8 -> 234.8 (-4.5 %)       N 768 / K 3072 213.0 -> 213.6
+//     in the forward (fc1 only, with the LayerNorm fold: 12 more constants per lane, the second column pair's requested
+//     behind the fill): gemm_ring4d_kernel<1, true> 250 us per launch against ring4's 249-258; step 9.048 -> 9.019 ms.
+// i.e. hiding the prologue behind the epilogue pays where the epilogue is long (GELU) and the output not the larger part of
+// the traffic; for qkv the 16-row x 64-B store instructions in place of whole 128-B lines cost more than the prologue (the
+// CU's address path is what both kernels wait on: DESIGN.md 4.7), and with the fold's constants the fc1 gain is gone too.
+// Findings worth keeping:
 //   * A HARDWARE HAZARD hipcc (ROCm 7.2) does not cover: `buffer_store_dwordx4 v[a:a+3], voff, rsrc, sN offen` -- an SGPR
 //     soffset -- followed IMMEDIATELY by a VALU write of v[a] can store the NEW value of that register (seen in lanes 12-15 of
 //     every 16, in the second wave of a SIMD, in ~1 % of the tiles of the K = 3072 launch: the first dword of the 16-byte
@@ -48,7 +51,6 @@
 //     striding lost 13 % on qkv in round 2: the hardware dispatcher's back-fill is a dynamic queue, and this is one.)
 // Same products in the same order and the same epilogue formulas as ring4: outputs are bitwise equal (tests/test_ops_gpu.py).
 #define R4D_STORE_NOP 1
-#define R4D_BUILTIN_DRAW 1  // (the asm draw faults: see the header)
 #include <mutex>
 
 #include "gemm_kernels.h"
@@ -62,7 +64,7 @@ VDR_DEV int swzd(int row) { return (-(row >> 3)) & 3; }
 
 
 template <int EPI, bool FOLD>
-__global__ __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(127))) void gemm_ring4d_kernel(GemmK p, int* __restrict__ queue) {
+__global__ __launch_bounds__(512, 4) void gemm_ring4d_kernel(GemmK p, int* __restrict__ queue) {
   static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "write-once outputs only");
   constexpr int WAVES_N = 4;
   constexpr int BM = 128, BN = 256;
@@ -133,22 +135,22 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(127))) void 
     stage_a(1);
     stage_w(2);
   };
-  // one draw from this XCD's counter: the id of the tile after the next one (-> s_next one tile later)
-  int drawn = 0;  // (thread 0 only) the last value drawn from this XCD's counter: the id of the tile after the next one
-  const int ids_here = (p.nwg - xcd + 7) >> 3;  // tile ids congruent to xcd (mod 8)
+  // Tile sequence of workgroup b: a STATIC head, ids b, b + G, ..., b + (n_static - 1) G (every workgroup can work that out
+  // for itself: no draw, no mailbox, one barrier between tiles), then a DYNAMIC tail drawn from this XCD's counter over the
+  // ids from n_static G on (what evens out the end of the launch: static striding alone lost 13 % on qkv in round 2).  A
+  // draw goes through atomicAdd, behind which hipcc's atomic optimizer waits vmcnt(0) -- thread 0's wave then sits out its
+  // own fill -- so it is confined to the last tiles of a workgroup.
+  const int n_static = max(1, p.nwg / G - 1);
+  const int dyn_base = n_static * (G >> 3);                   // draws number the ids xcd + 8 (dyn_base + v)
+  const int ids_here = (p.nwg - xcd + 7) >> 3;                // tile ids congruent to xcd (mod 8)
+  const int last_v = ids_here - dyn_base + (G >> 3) - 1;      // the last value this XCD's counter ever hands out
+  int drawn = 0;  // (thread 0 only) the last value drawn: the id of the tile after the next one
+  int t = 0;      // index of the current tile in this workgroup's sequence
 
   int id = blockIdx.x;
   setup(id);
   fill();
-#ifdef R4D_BUILTIN_DRAW
-  if (threadIdx.x == 0) drawn = atomicAdd(queue + xcd, 1);
-#else
-  if (threadIdx.x == 0) {
-    const int one = 1;
-    asm volatile("global_atomic_add v127, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v127"
-                 : "=v"(drawn) : "v"(xcd * 4), "v"(one), "s"(queue) : "memory", "v127");
-  }
-#endif
+  if (1 >= n_static && threadIdx.x == 0) drawn = atomicAdd(queue + xcd, 1);
   bool first = true;
   for (;;) {
     int tid = threadIdx.x;
@@ -275,43 +277,38 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(127))) void 
         stats[i] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * m);
       }
     }
-    // the id of the next tile (drawn a tile ago) goes to every wave through LDS: written into the A slot nobody reads any
-    // more (every wave is past the barrier of step nsteps - 2), read behind the barrier that frees the ring, and a second
-    // barrier keeps a fast wave's fill from overwriting it before a slow wave has read it
-    // (an LDS-typed pointer: through a generic `volatile int*` hipcc emitted flat_store / flat_load with vmcnt(0) waits)
-    typedef __attribute__((address_space(3))) int lds_int;
-    lds_int* s_next = (lds_int*)(smem + ((((nsteps >> 1) - 1) & 1) ^ 1) * APIECE);
-    if (threadIdx.x == 0) *s_next = xcd + 8 * ((G >> 3) + drawn);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    const bool next_static = t + 1 < n_static;  // wave-uniform
+    int nid;
     const int last_draw = drawn;
-    int nid_v = *s_next;
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nid_v) : : "memory");
-    const int nid = __builtin_amdgcn_readfirstlane(nid_v);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if (next_static) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done with the ring
+      asm volatile("" ::: "memory");
+      nid = blockIdx.x + (t + 1) * G;
+    } else {
+      // the id of the next tile (drawn a tile ago) goes to every wave through LDS: written into the A slot nobody reads any
+      // more (every wave is past the barrier of step nsteps - 2), read behind the barrier that frees the ring, and a second
+      // barrier keeps a fast wave's fill from overwriting it before a slow wave has read it
+      // (an LDS-typed pointer: through a generic `volatile int*` hipcc emitted flat_store / flat_load with vmcnt(0) waits)
+      typedef __attribute__((address_space(3))) int lds_int;
+      lds_int* s_next = (lds_int*)(smem + ((((nsteps >> 1) - 1) & 1) ^ 1) * APIECE);
+      if (threadIdx.x == 0) *s_next = xcd + 8 * (dyn_base + drawn);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int nid_v = *s_next;
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nid_v) : : "memory");
+      nid = __builtin_amdgcn_readfirstlane(nid_v);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     const bool more = (uint32_t)nid < (uint32_t)p.nwg;  // wave-uniform (unsigned: whatever the mailbox held, never an id outside the tile list)
     const int64_t mw_this = mw;
-    // ---- the draw for the tile after the next one, by thread 0, as ONE opaque instruction behind the fill; its result is
-    //      waited for at the end of the epilogue.  (Through atomicAdd hipcc's atomic optimizer counts the active lanes, lets
-    //      one of them add the count and reads the result back with v_readfirstlane behind a vmcnt(0) of its own: thread
-    //      0's wave would sit out its own fill before its epilogue.)  `drawn` is touched by nothing between the two
-    //      statements: it lands in v127, which hipcc does not allocate (amdgpu_num_vgpr(127) on the kernel; the wave still
-    //      gets 128) -- as a C++ variable hipcc copied it to another register right behind the instruction, before the data
-    //      had arrived.
     if (more) {
       setup(nid);
       fill();
-#ifdef R4D_BUILTIN_DRAW
-      if (threadIdx.x == 0) drawn = atomicAdd(queue + xcd, 1);
-#else
-      if (threadIdx.x == 0) {
-        const int one = 1;
-        asm volatile("global_atomic_add v127, %0, %1, %2 sc0" : : "v"(xcd * 4), "v"(one), "s"(queue) : "memory", "v127");
-      }
-#endif
-    } else if (threadIdx.x == 0 && last_draw == ids_here - 1) {
+      if (t + 2 >= n_static && threadIdx.x == 0) drawn = atomicAdd(queue + xcd, 1);  // the tile after the next one is a dynamic one
+    } else if (threadIdx.x == 0 && last_draw == last_v) {
       // this workgroup's draw failed; it was the last draw its XCD will ever make: the counter goes back to zero
       atomicExch(queue + xcd, 0);
     }
@@ -362,12 +359,9 @@ __global__ __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(127))) void 
         if (jp == 0) __builtin_amdgcn_sched_barrier(0);  // (the second pair's arithmetic stays behind the first pair's stores)
       }
     }
-    // the draw issued behind the fill has returned: everything older than this tile's 8 stores has (vmcnt retires in order)
-#ifndef R4D_BUILTIN_DRAW
-    if (more) asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32 %0, v127" : "=v"(drawn) : "n"(NSTORE) : "memory");
-#endif
     if (!more) break;
     id = nid;
+    ++t;
   }
 }
 
