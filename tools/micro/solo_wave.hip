@@ -3,8 +3,11 @@
 // One 4-wave workgroup per CU, 2 x 2 waves of 128 x 128 over a 256 x 256 tile; per 64-deep step a wave does 128 MFMAs
 // (16x16x32) = 2048 pipe cycles, 32 ds_read_b128 of fragments and, optionally, its 16 of the step's 64 LDS-DMA pieces and
 // one s_barrier.  Nothing is computed that means anything: LDS holds whatever it holds, the loads go to the other stage.
-//   hipcc --offload-arch=gfx950 -O3 -o solo_wave solo_wave.hip && ./solo_wave <loads 0|1> <barrier 0|1> [steps] [wait 0|1|2]
+//   hipcc --offload-arch=gfx950 -O3 -o solo_wave solo_wave.hip && ./solo_wave <loads 0|1|2> <barrier 0|1> [steps] [wait 0|1|2]   (loads 2: global_load_dwordx4 -> VGPR -> ds_write_b128 one step later)
 // Prints cycles per step per wave (s_memtime) against the 2048 of the pipe.
+// (loads 2 -- register-staged -- is NOT a measurement of that path as it compiles today: with 256 accumulator registers in
+// AGPRs hipcc keeps the 16 staged registers there too and rotates them through v_accvgpr_mov / read / write chains in the
+// loop: 0.7 PF.  It needs the staging registers pinned, i.e. an assembly loop.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +34,7 @@ __device__ __forceinline__ void dma_piece(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");
 }
 
-template <bool LOADS, bool BARRIER, int WAIT>
+template <int LOADS, bool BARRIER, int WAIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k(const char* __restrict__ src, long src_bytes,
                                                                                     int steps, float* sink,
                                                                                     unsigned long long* cyc) {
@@ -55,6 +58,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else fb[set][t] = v;
   };
   const char* g = src + ((long)blockIdx.x * 65536 + wave * 16384 + lane * 16) % (src_bytes - (1 << 20));
+  i32x4 stg[16];
+  if (LOADS == 2) static_for<16>([&](auto i) { stg[i] = *reinterpret_cast<const i32x4*>(g + i * 1024); });
   static_for<16>([&](auto i) { read_frag(std::integral_constant<int, 0>{}, i, 0u, 0); });
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
@@ -65,9 +70,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       static_for<16>([&](auto grp) {
         // the fragment set of the next k half (the next step's first half from the other stage when kk == 1)
         read_frag(std::integral_constant<int, oset>{}, grp, kk == 0 ? cur : nxt, kk == 0 ? 1 : 0);
-        if constexpr (LOADS && (grp % 2 == 0)) {
+        if constexpr (LOADS == 1 && (grp % 2 == 0)) {
           constexpr int piece = kk * 8 + grp / 2;  // 16 pieces per wave per step
           dma_piece(g + piece * 1024, (unsigned)(uintptr_t)lds + nxt + (wave * 16 + piece) * 1024);
+        }
+        if constexpr (LOADS == 2 && (grp % 2 == 0)) {
+          // register-staged: the piece loaded ONE step ago goes to LDS (ds_write_b128), its register takes the next load
+          constexpr int piece = kk * 8 + grp / 2;
+          *reinterpret_cast<__attribute__((address_space(3))) i32x4*>((uintptr_t)((unsigned)(uintptr_t)lds + nxt + (wave * 16 + piece) * 1024 + lane * 16)) = stg[piece];
+          stg[piece] = *reinterpret_cast<const i32x4*>(g + piece * 1024);
         }
         static_for<4>([&](auto e) {
           constexpr int m = grp * 4 + e, i = m / 8, j = m % 8;
@@ -81,14 +92,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (g + 65536 > src + src_bytes) g -= (src_bytes - (2 << 20));
       // WAIT 0: everything issued in this step has landed (a 2-stage ring with no slack); 1: everything issued in the
       // PREVIOUS step has (the 16 pieces of this step may be in flight: one step of slack); 2: no wait (the address path alone)
-      if (WAIT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (WAIT == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if (LOADS == 1 && WAIT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (LOADS == 1 && WAIT == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     if (BARRIER) __builtin_amdgcn_s_barrier();
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
   float sum = 0.f;
   static_for<64>([&](auto m) { sum += acc[m / 8][m % 8][0] + acc[m / 8][m % 8][3]; });
+  if (LOADS == 2) static_for<16>([&](auto i) { sum += (float)stg[i][0]; });
   if (sum == 123456.789f) sink[lane] = sum;
   if (lane == 0 && blockIdx.x == 7) cyc[wave] = t1 - t0;
 }
@@ -125,8 +137,9 @@ int main(int argc, char** argv) {
     return 0;
   };
   const int wait = argc > 4 ? atoi(argv[4]) : 0;
-  if (loads && barrier) return wait == 0 ? run(k<true, true, 0>) : wait == 1 ? run(k<true, true, 1>) : run(k<true, true, 2>);
-  if (loads) return wait == 0 ? run(k<true, false, 0>) : wait == 1 ? run(k<true, false, 1>) : run(k<true, false, 2>);
-  if (barrier) return run(k<false, true, 0>);
-  return run(k<false, false, 0>);
+  if (loads == 2) return barrier ? run(k<2, true, 2>) : run(k<2, false, 2>);  // register-staged loads (hipcc counts the waits itself)
+  if (loads && barrier) return wait == 0 ? run(k<1, true, 0>) : wait == 1 ? run(k<1, true, 1>) : run(k<1, true, 2>);
+  if (loads) return wait == 0 ? run(k<1, false, 0>) : wait == 1 ? run(k<1, false, 1>) : run(k<1, false, 2>);
+  if (barrier) return run(k<0, true, 0>);
+  return run(k<0, false, 0>);
 }
