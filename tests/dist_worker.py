@@ -80,8 +80,9 @@ def main():
             if probe is not None:
                 dist.all_gather_into_tensor(probe, mine.contiguous())
             torch.cuda.synchronize()
-            res["ok"] = bool(torch.equal(got, whole) and got.is_contiguous() and got.dtype == torch.float32
-                             and (probe is None or torch.equal(probe, whole)))
+            res["checks"] = {"gathered == whole": bool(torch.equal(got, whole)), "contiguous fp32": bool(got.is_contiguous() and got.dtype == torch.float32),
+                             "explicit collective == whole": bool(probe is None or torch.equal(probe, whole))}
+            res["ok"] = all(res["checks"].values())
             res["rows"] = [lo, hi]
             # the overlapped step of bench.py --gpus N: micro-batches gathered on a side stream, both transfer paths
             from vdr.dist import OverlappedGather
