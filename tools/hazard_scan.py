@@ -4,7 +4,7 @@
 Found with tools/micro/gemm_ring4d_experiment.hip (round 3): `buffer_store_dwordx4 v[a:a+3], voff, rsrc, sN offen` -- a
 MUBUF store of more than 64 bits whose soffset is an SGPR -- followed at once by a VALU write of one of its data registers
 can store the NEW register value (LLVM's hazard recognizer inserts the wait state only when the soffset is not a
-register).  Two wait states behind the store fix it.  This script lists every such store that is followed, within
+register).  One wait state -- any instruction -- between the two is enough.  This script lists every such store that is followed, within
 `--window` instructions, by a vector instruction writing one of its data registers.
 
     python tools/hazard_scan.py                 # compiles csrc/*.hip to ISA with hipcc (-S) and scans them

@@ -15,8 +15,9 @@
 //     soffset -- followed IMMEDIATELY by a VALU write of v[a] can store the NEW value of that register (seen in lanes 12-15 of
 //     every 16, in the second wave of a SIMD, in ~1 % of the tiles of the K = 3072 launch: the first dword of the 16-byte
 //     store held the next block's unconverted fp32 sum).  LLVM's hazard recognizer inserts the wait state only when the
-//     soffset is NOT a register.  Two wait states behind the store, tied to its data registers so that the scheduler cannot
-//     move the write in front of them (R4D_STORE_NOP below), make the kernel bit-exact; tools/hazard_scan.py looks for the
+//     soffset is NOT a register.  One wait state is enough (a build with an s_and_b64 between the two: 40 clean launches;
+//     with nothing between them ~500 wrong elements per launch).  R4D_STORE_NOP below ties an s_nop to the store's data
+//     registers so that the scheduler cannot move the write in front of it; tools/hazard_scan.py looks for the
 //     pattern in the library's ISA (none: the shipped stores with an SGPR soffset are followed by other stores or the end).
 //   * with the draw as an opaque `global_atomic_add v127 ... sc0` (v127 kept out of hipcc's hands by amdgpu_num_vgpr(127))
 //     the kernel raises a memory access fault on its first multi-tile launch, with or without wait states behind the
