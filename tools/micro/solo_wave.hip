@@ -3,11 +3,13 @@
 // One 4-wave workgroup per CU, 2 x 2 waves of 128 x 128 over a 256 x 256 tile; per 64-deep step a wave does 128 MFMAs
 // (16x16x32) = 2048 pipe cycles, 32 ds_read_b128 of fragments and, optionally, its 16 of the step's 64 LDS-DMA pieces and
 // one s_barrier.  Nothing is computed that means anything: LDS holds whatever it holds, the loads go to the other stage.
-//   hipcc --offload-arch=gfx950 -O3 -o solo_wave solo_wave.hip && ./solo_wave <loads 0|1|2> <barrier 0|1> [steps] [wait 0|1|2]   (loads 2: global_load_dwordx4 -> VGPR -> ds_write_b128 one step later)
+//   hipcc --offload-arch=gfx950 -O3 -o solo_wave solo_wave.hip && ./solo_wave <loads 0|1|2> <barrier 0|1> [steps] [wait 0|1|2]   (loads 2 / 3: global_load_dwordx4 -> VGPR -> ds_write_b128 one step later, as C++ / as opaque instructions)
 // Prints cycles per step per wave (s_memtime) against the 2048 of the pipe.
-// (loads 2 -- register-staged -- is NOT a measurement of that path as it compiles today: with 256 accumulator registers in
-// AGPRs hipcc keeps the 16 staged registers there too and rotates them through v_accvgpr_mov / read / write chains in the
-// loop: 0.7 PF.  It needs the staging registers pinned, i.e. an assembly loop.)
+// (loads 2 -- register-staged as C++ -- is NOT a measurement of that path: with 256 accumulator registers in AGPRs hipcc keeps
+// the 16 staged registers there too and rotates them through v_accvgpr_mov / read / write chains in the loop: 0.7 PF.
+// loads 3 issues the same loads and ds_writes as opaque instructions with a counted vmcnt(15): the staged data stays put,
+// but with 64 more live VGPRs hipcc renames accumulator tuples through 64 v_accvgpr_mov + s_nop per step; 1.24-1.34 PF
+// without and 0.96-1.17 PF with the barrier -- below the LDS-DMA form (1.63-1.72 / 1.26-1.42) even allowing for that.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +62,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const char* g = src + ((long)blockIdx.x * 65536 + wave * 16384 + lane * 16) % (src_bytes - (1 << 20));
   i32x4 stg[16];
   if (LOADS == 2) static_for<16>([&](auto i) { stg[i] = *reinterpret_cast<const i32x4*>(g + i * 1024); });
+  if (LOADS == 3) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[i]) : "v"(g + i * 1024) : "memory");
+  }
   static_for<16>([&](auto i) { read_frag(std::integral_constant<int, 0>{}, i, 0u, 0); });
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
@@ -73,6 +79,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (LOADS == 1 && (grp % 2 == 0)) {
           constexpr int piece = kk * 8 + grp / 2;  // 16 pieces per wave per step
           dma_piece(g + piece * 1024, (unsigned)(uintptr_t)lds + nxt + (wave * 16 + piece) * 1024);
+        }
+        if constexpr (LOADS == 3 && (grp % 2 == 0)) {
+          // register-staged, every memory instruction opaque: hipcc cannot move the staged data anywhere.  The piece loaded
+          // one step ago is the oldest of the 16 loads in flight: vmcnt(15)
+          constexpr int piece = kk * 8 + grp / 2;
+          const unsigned dst = (unsigned)(uintptr_t)lds + nxt + (wave * 16 + piece) * 1024 + lane * 16;
+          asm volatile("s_waitcnt vmcnt(15)\n\tds_write_b128 %0, %1" : : "v"(dst), "v"(stg[piece]) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[piece]) : "v"(g + piece * 1024) : "memory");
         }
         if constexpr (LOADS == 2 && (grp % 2 == 0)) {
           // register-staged: the piece loaded ONE step ago goes to LDS (ds_write_b128), its register takes the next load
@@ -90,6 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (LOADS) {
       g += 16384 * 4;
       if (g + 65536 > src + src_bytes) g -= (src_bytes - (2 << 20));
+      if (LOADS == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the ds_writes are opaque: hipcc does not wait for them)
       // WAIT 0: everything issued in this step has landed (a 2-stage ring with no slack); 1: everything issued in the
       // PREVIOUS step has (the 16 pieces of this step may be in flight: one step of slack); 2: no wait (the address path alone)
       if (LOADS == 1 && WAIT == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -100,7 +115,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const unsigned long long t1 = __builtin_readcyclecounter();
   float sum = 0.f;
   static_for<64>([&](auto m) { sum += acc[m / 8][m % 8][0] + acc[m / 8][m % 8][3]; });
-  if (LOADS == 2) static_for<16>([&](auto i) { sum += (float)stg[i][0]; });
+  if (LOADS >= 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<16>([&](auto i) { sum += (float)stg[i][0]; });
+  }
   if (sum == 123456.789f) sink[lane] = sum;
   if (lane == 0 && blockIdx.x == 7) cyc[wave] = t1 - t0;
 }
@@ -137,6 +155,7 @@ int main(int argc, char** argv) {
     return 0;
   };
   const int wait = argc > 4 ? atoi(argv[4]) : 0;
+  if (loads == 3) return barrier ? run(k<3, true, 2>) : run(k<3, false, 2>);  // register-staged, opaque instructions
   if (loads == 2) return barrier ? run(k<2, true, 2>) : run(k<2, false, 2>);  // register-staged loads (hipcc counts the waits itself)
   if (loads && barrier) return wait == 0 ? run(k<1, true, 0>) : wait == 1 ? run(k<1, true, 1>) : run(k<1, true, 2>);
   if (loads) return wait == 0 ? run(k<1, false, 0>) : wait == 1 ? run(k<1, false, 1>) : run(k<1, false, 2>);
