@@ -1,6 +1,8 @@
 """Rank process for the multi-rank tests, started by vdr.dist.launch_ranks (the launcher bench.py uses).
 
     --backend gloo : CPU tensors; the per-rank "forward" is an identity on a known matrix (no GPU needed)
+    --backend gloo --device cuda : every rank shares cuda:0 and runs the HIP forward; gloo moves the device rows through
+                     the host with no stream ordering, so OverlappedGather synchronises before each post (no side stream)
     --backend nccl : one rank per GPU (RCCL); every rank runs the HIP forward on its batch shard, the shards are
                      all-gathered and compared BITWISE with that rank's own forward of the whole batch
 
@@ -26,6 +28,7 @@ def main():
     ap.add_argument("--total", type=int, default=8)
     ap.add_argument("--dim", type=int, default=5)
     ap.add_argument("--out", required=True)
+    ap.add_argument("--device", default="cpu", choices=["cpu", "cuda"])
     a = ap.parse_args()
     from vdr.dist import all_gather_rows, extract_features_sharded, init_from_env, shard_bounds
 
@@ -33,7 +36,7 @@ def main():
     res = {"rank": rank, "world": world, "backend": dist.get_backend(), "group_size": dist.get_world_size()}
     try:
         lo, hi = shard_bounds(a.total, rank, world)
-        if a.backend == "gloo":
+        if a.backend == "gloo" and a.device == "cpu":
             full = torch.arange(a.total * a.dim, dtype=torch.float32).reshape(a.total, a.dim) * 0.5 - 3.0
             calls = []
 
@@ -64,10 +67,27 @@ def main():
                         good = bool(torch.equal(got, want) and got.data_ptr() == feats.data_ptr() and covered)
                         res["overlap"][f"{str(dt)[6:]}/{mode}/{chunks}"] = [good, og.mode, og.chunks]
                         res["ok"] = res["ok"] and good
+            # ragged shards on both sides of the mesh threshold: the plan must come out the same on every rank (it is
+            # made from the largest shard), or the ranks post different numbers of transfers and hang
+            import vdr.dist as vd
+            sizes = sorted({shard_bounds(a.total, r, world)[1] - shard_bounds(a.total, r, world)[0] for r in range(world)})
+            if len(sizes) == 2:
+                keep = vd.MESH_THRESHOLD_BYTES
+                vd.MESH_THRESHOLD_BYTES = (sizes[0] * a.dim * 4 + sizes[1] * a.dim * 4) // 2
+                try:
+                    feats = torch.full((a.total, a.dim), -77.0)
+                    og = OverlappedGather(feats, a.total, chunks=0, mode="auto")
+                    got = og.run(lambda x0, x1, rows: rows.copy_(full[lo + x0: lo + x1]))
+                    good = bool(torch.equal(got, full))
+                    res["straddle"] = [good, og.mode, og.chunks]
+                    res["ok"] = res["ok"] and good and og.mode == "mesh" and og.chunks == min(4, sizes[1])
+                finally:
+                    vd.MESH_THRESHOLD_BYTES = keep
         else:
             import vdr
             from oracle import vit_oracle as vo
-            torch.cuda.set_device(local_rank)
+            shared = a.backend == "gloo"  # every rank on cuda:0 (one-GPU box): gloo carries the device rows
+            torch.cuda.set_device(0 if shared else local_rank)
             cfg = vo.VitCfg(64, 16, 3, 128, 2, 2, 512)
             eng = vdr.Engine(vdr.VdrConfig(img=64, patch=16, dim=128, heads=2, layers=2, mlp_hidden=512))
             eng.load_weights(vo.make_weights(cfg, seed=1, scale=0.05))
@@ -91,6 +111,7 @@ def main():
                 for chunks in (1, 2):
                     feats = torch.full_like(whole, -77.0)
                     og = OverlappedGather(feats, a.total, chunks=chunks, mode=mode)
+                    assert (og.side is None) == (shared or world == 1), "side stream only behind a stream-ordered transport"
                     og.run(lambda x0, x1, rows: eng.forward_into(x[lo + x0: lo + x1].contiguous(), rows, vdr.OUT_CLS))
                     torch.cuda.synchronize()
                     good = bool(torch.equal(feats, whole))

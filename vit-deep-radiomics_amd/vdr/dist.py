@@ -118,7 +118,8 @@ def gather_plan(rows_local_bytes: int, chunks: int = 0, mode: str = "auto"):
     """(chunks, mode) for a per-rank message of that many bytes: small messages (the [B, D] CLS matrix: < 1 MB per
     rank) go out as ONE collective after the forward -- splitting the forward would cost more than the gather takes;
     large ones (dense per-patch descriptors: 75 MB per rank and step at BASELINE config 4) are cut in 4 micro-batches
-    whose gathers run on a side stream under the next micro-batch's kernels, point to point over the full xGMI mesh."""
+    whose gathers run on a side stream under the next micro-batch's kernels, point to point over the full xGMI mesh.
+    The caller passes a RANK-INVARIANT size (the largest shard): every rank must arrive at the same plan."""
     big = rows_local_bytes > MESH_THRESHOLD_BYTES
     if chunks <= 0:
         chunks = 4 if big else 1
@@ -129,40 +130,130 @@ def gather_plan(rows_local_bytes: int, chunks: int = 0, mode: str = "auto"):
     return chunks, mode
 
 
-class OverlappedGather:
-    """One data-parallel extraction step: this rank's forward writes its rows STRAIGHT into its slice of the final
-    row-ordered [N, ...] matrix, micro-batch by micro-batch, and every finished micro-batch is sent to the peers while the
-    next one computes.
+class GroupTransport:
+    """The peers are the ranks of a torch.distributed process group.
 
     mode "collective": all_gather_into_tensor per micro-batch into a [world, rows, ...] staging buffer + one strided
         device copy into the peers' row slices (RCCL picks the algorithm; equal shards only);
     mode "mesh": every rank posts, per micro-batch, one send of its rows to each peer and one receive from each peer
         DIRECTLY into that peer's row slice of the final matrix (batch_isend_irecv: RCCL runs the 2 (world - 1) transfers
         of a group concurrently, one per xGMI link of the point-to-point mesh; no staging, ragged shards welcome).
-    Pure copies either way: the matrix is bitwise the 1-rank result.
 
-    On a GPU the transfers are issued from a side stream that waits for the micro-batch's forward only (an event), so the
-    compute stream never waits for a transfer until `finish()`; on CPU tensors (gloo, the tests) the same calls run in
-    order.  `gather_ms` (GPU) is the time the transfers of the last step occupied the side stream."""
+    `stream_ordered`: only RCCL ("nccl") enqueues its transfers on the CUDA stream that is current when they are posted.
+    gloo hands a device pointer to its TCP transport -- the host reads VRAM with no ordering against any stream -- so for
+    device tensors on any other backend the owner synchronises the compute stream before every post and uses no side
+    stream."""
 
-    def __init__(self, feats: torch.Tensor, total_rows: int, chunks: int = 0, mode: str = "auto", group=None):
+    def __init__(self, group=None):
         self.group = group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.stream_ordered = dist.get_backend(group) == "nccl"
+        self._work, self._stage = [], None
+
+    def post(self, og, c: int):
+        feats = og.feats
+        if og.mode == "mesh":
+            ops = []
+            for k in range(1, self.world):  # staggered partners: every rank talks to a different peer in round k
+                dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
+                a, b = og.chunk_bounds(self.rank, c)
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, feats[a:b], dst, self.group))
+                a, b = og.chunk_bounds(src, c)
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, feats[a:b], src, self.group))
+            if ops:
+                self._work += dist.batch_isend_irecv(ops)
+            return
+        a, b = og.chunk_bounds(self.rank, c)
+        n = b - a
+        if n == 0:
+            return
+        if og.chunks == 1:  # the whole shard at once: the in-place collective (input = this rank's slice of the output)
+            dist.all_gather_into_tensor(feats, feats[a:b], group=self.group, async_op=True).wait()
+            return
+        tail = tuple(feats.shape[1:])
+        if self._stage is None:
+            mx = max(og.chunk_bounds(self.rank, cc)[1] - og.chunk_bounds(self.rank, cc)[0] for cc in range(og.chunks))
+            self._stage = torch.empty((self.world, mx) + tail, dtype=feats.dtype, device=feats.device)
+        stage = self._stage if self._stage.shape[1] == n else None
+        if stage is None:  # (the last micro-batch of an uneven split: a contiguous staging buffer of its own size)
+            stage = torch.empty((self.world, n) + tail, dtype=feats.dtype, device=feats.device)
+        # .wait() orders the current (side) stream behind the collective; the compute stream is not involved
+        dist.all_gather_into_tensor(stage.view((self.world * n,) + tail), feats[a:b], group=self.group, async_op=True).wait()
+        for r in range(self.world):
+            if r != self.rank:
+                ra, rb = og.chunk_bounds(r, c)
+                feats[ra:rb].copy_(stage[r])
+
+    def finish(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+
+class LoopbackTransport:
+    """ONE process plays `world` ranks on one device: the peers' rows come from `peer_rows` (a complete [N, ...] matrix,
+    e.g. the whole-batch forward) by device-to-device copies, and what this rank "sends" is copied into `sent` -- all
+    enqueued on the stream that is current at post(), i.e. OverlappedGather's side stream.  It exists so that the event /
+    side-stream / finish() wiring of the overlapped step runs on a device where only one GPU is visible
+    (tests/test_dist_gpu.py): a post that is not ordered behind its micro-batch's forward shows up as stale rows in `sent`."""
+    stream_ordered = True
+
+    def __init__(self, world: int, rank: int, peer_rows: torch.Tensor):
+        assert 0 <= rank < world
+        self.world, self.rank, self.peer = world, rank, peer_rows
+        self.sent = torch.full_like(peer_rows, float("nan")) if peer_rows.is_floating_point() else torch.zeros_like(peer_rows)
+        self.posts = []
+
+    def post(self, og, c: int):
+        assert og.feats.shape == self.peer.shape
+        a, b = og.chunk_bounds(self.rank, c)
+        if b > a:
+            self.sent[a:b].copy_(og.feats[a:b], non_blocking=True)       # the "isend" of this micro-batch
+        for r in range(self.world):
+            if r != self.rank:
+                ra, rb = og.chunk_bounds(r, c)
+                if rb > ra:
+                    og.feats[ra:rb].copy_(self.peer[ra:rb], non_blocking=True)  # the "irecv" from peer r
+        self.posts.append((c, torch.cuda.current_stream(og.feats.device).cuda_stream if og.feats.is_cuda else None))
+
+    def finish(self):
+        pass
+
+
+class OverlappedGather:
+    """One data-parallel extraction step: this rank's forward writes its rows STRAIGHT into its slice of the final
+    row-ordered [N, ...] matrix, micro-batch by micro-batch, and every finished micro-batch is sent to the peers while the
+    next one computes.  The transfers belong to a transport (`post(og, c)`, `finish()`): GroupTransport (RCCL / gloo
+    process group, "mesh" or "collective") or LoopbackTransport (one process playing every rank).  Pure copies either way:
+    the matrix is bitwise the 1-rank result.
+
+    With device tensors and a stream-ordered transport the transfers are issued from a side stream that waits for the
+    micro-batch's forward only (an event), so the compute stream never waits for a transfer until `finish()`; with a
+    transport that ignores streams (gloo on device tensors) the compute stream is synchronised before every post; on CPU
+    tensors (gloo, the tests) the same calls run in order.  `gather_ms` (GPU) is the time the transfers of the last step
+    occupied the side stream."""
+
+    def __init__(self, feats: torch.Tensor, total_rows: int, chunks: int = 0, mode: str = "auto", group=None, transport=None):
+        self.transport = transport if transport is not None else GroupTransport(group)
+        self.world, self.rank = self.transport.world, self.transport.rank
         assert feats.shape[0] == total_rows and feats.is_contiguous()
         self.feats, self.total = feats, total_rows
         self.bounds = [shard_bounds(total_rows, r, self.world) for r in range(self.world)]
-        lo, hi = self.bounds[self.rank]
         row_bytes = feats[0].numel() * feats.element_size() if total_rows else 0
-        self.chunks, self.mode = gather_plan((hi - lo) * row_bytes, chunks, mode)
-        # (the same count on every rank whatever its own shard holds: the ranks pair their transfers per micro-batch)
-        self.chunks = max(1, min(self.chunks, max(b - a for a, b in self.bounds) or 1))
+        largest = max(b - a for a, b in self.bounds)
+        # planned from the LARGEST shard, which every rank computes alike: ranks whose own ragged shards straddle
+        # MESH_THRESHOLD_BYTES would otherwise post different numbers of transfers per step
+        self.chunks, self.mode = gather_plan(largest * row_bytes, chunks, mode)
+        self.chunks = max(1, min(self.chunks, largest or 1))
         sizes = {b - a for a, b in self.bounds}
         if self.mode == "collective" and len(sizes) != 1:
             self.mode = "mesh"  # ragged shards: the point-to-point path needs no padding
         self.cuda = feats.is_cuda
-        self.side = torch.cuda.Stream(device=feats.device) if self.cuda and self.world > 1 else None
-        self._stage = None
-        self._work, self._events = [], []
+        self.stream_ordered = bool(getattr(self.transport, "stream_ordered", False))
+        self.side = torch.cuda.Stream(device=feats.device) if (self.cuda and self.world > 1 and self.stream_ordered) else None
+        self._events = []
         self.gather_ms = None
 
     def my_rows(self):
@@ -193,60 +284,21 @@ class OverlappedGather:
                     if c == 0:
                         t0 = torch.cuda.Event(enable_timing=True)
                         t0.record()
-                    self._post(c)
+                    self.transport.post(self, c)
                     if c == self.chunks - 1:
                         t1 = torch.cuda.Event(enable_timing=True)
                         t1.record()
             else:
-                self._post(c)
+                if self.cuda:  # a transport that does not follow streams reads the rows from the host side: they must be there
+                    torch.cuda.current_stream(self.feats.device).synchronize()
+                self.transport.post(self, c)
         self.finish()
         if t0 is not None and t1 is not None:
             self._events = [(t0, t1)]
         return self.feats
 
-    def _post(self, c: int):
-        if self.mode == "mesh":
-            ops = []
-            for k in range(1, self.world):  # staggered partners: every rank talks to a different peer in round k
-                dst, src = (self.rank + k) % self.world, (self.rank - k) % self.world
-                a, b = self.chunk_bounds(self.rank, c)
-                if b > a:
-                    ops.append(dist.P2POp(dist.isend, self.feats[a:b], dst, self.group))
-                a, b = self.chunk_bounds(src, c)
-                if b > a:
-                    ops.append(dist.P2POp(dist.irecv, self.feats[a:b], src, self.group))
-            if ops:
-                self._work += dist.batch_isend_irecv(ops)
-            return
-        a, b = self.chunk_bounds(self.rank, c)
-        n = b - a
-        if n == 0:
-            return
-        if self.chunks == 1:  # the whole shard at once: the in-place collective (input = this rank's slice of the output)
-            w = dist.all_gather_into_tensor(self.feats, self.feats[a:b], group=self.group, async_op=True)
-            w.wait()
-            return
-        if self._stage is None or self._stage.shape[1] < n:
-            mx = max(self.chunk_bounds(self.rank, cc)[1] - self.chunk_bounds(self.rank, cc)[0] for cc in range(self.chunks))
-            self._stage = torch.empty((self.world, mx) + tuple(self.feats.shape[1:]), dtype=self.feats.dtype, device=self.feats.device)
-        stage = self._stage[:, :n] if self._stage.shape[1] == n else None
-        if stage is None:  # (the last micro-batch of an uneven split: a contiguous staging view of its own size)
-            stage = torch.empty((self.world, n) + tuple(self.feats.shape[1:]), dtype=self.feats.dtype, device=self.feats.device)
-        w = dist.all_gather_into_tensor(stage.view((self.world * n,) + tuple(self.feats.shape[1:])), self.feats[a:b], group=self.group,
-                                        async_op=True)
-        if self.side is None:
-            w.wait()
-        else:
-            w.wait()  # (orders the side stream behind the collective; the compute stream is not involved)
-        for r in range(self.world):
-            if r != self.rank:
-                ra, rb = self.chunk_bounds(r, c)
-                self.feats[ra:rb].copy_(stage[r])
-
     def finish(self):
-        for w in self._work:
-            w.wait()
-        self._work = []
+        self.transport.finish()
         if self.side is not None:
             torch.cuda.current_stream(self.feats.device).wait_stream(self.side)
 
