@@ -1,0 +1,502 @@
+// The 256 x 256 x 64 "8-phase" GEMM structure of cdna_hip_programming.md §5 (The 256^2 8-phase template), written from its
+// description for the shapes of this library and measured against ring4 (csrc/gemm_kernels.h) IN ONE PROCESS on the same
+// random operands (the round-3 review's item 2: settle the GEMM ceiling with a known-good geometry, not with variants
+// of our own).   C[M, N] = A[M, K] . W[N, K]^T + bias,  bf16 in / out, fp32 accumulate, v_mfma_f32_16x16x32_bf16.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm8p gemm8p.hip -ldl && ./gemm8p [M] [rounds] [path/to/libvdr.so]
+//
+// Structure (one 512-thread workgroup per CU, persistent over a static tile list):
+//   * 8 waves = 2 (M) x 4 (N); a wave owns 128 x 64 of the 256 x 256 tile = 8 x 4 accumulator tiles (128 registers).
+//   * LDS: 2 K-tile buffers x {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255} x [128 rows][128 B] = 128 KB,
+//     every half-tile filled by 2 LDS-DMA instructions per thread (8 rows x 128 B = whole lines per wave-instruction),
+//     16-byte chunks XOR-swizzled on the source address and on the ds_read_b128 address (conflict-free fragment reads).
+//   * A K-tile (64 deep) is 4 phases of 16 MFMAs (one 64 x 32 quadrant of the wave tile x K = 64); each phase is
+//         ds_read fragments | issue one half-tile of LDS-DMA | [counted vmcnt] | lgkmcnt(0) | s_barrier |
+//         s_setprio 1 | 16 MFMAs | s_setprio 0 | s_barrier
+//     and the waves of the second M half (waves 4-7: the second wave of every SIMD) run ONE barrier behind the first half,
+//     so on a SIMD one wave's MFMA segment always faces the other wave's load segment (ping-pong).
+//   * The DMA stream never drains: K-tile t+1's half-tiles are issued while t is computed (a half-tile is re-staged one
+//     phase after the lgkmcnt + barrier that retired its last read: A1 + W0 in a K-tile's 1st phase, W1 in its 2nd, A0
+//     of t+2 in its 4th), the counted vmcnt(2) at the 4th phase leaves that half-tile in flight, and the stream runs on
+//     ACROSS output tiles (the next tile's first two K-tiles are in
+//     flight under this tile's last phases: no ring fill, no drain).
+//   * Epilogue without a separate phase: a quadrant of the accumulator is final after the last K-tile's phase that owns
+//     it, and is converted and stored in the LOAD segment of the following phase (facing the partner wave's MFMAs); the
+//     first MFMA of the next tile into that quadrant starts from C = 0.  W rows are permuted inside a 32-column block so
+//     that a lane's registers of two neighbouring accumulator tiles are 8 consecutive columns: 16-byte stores straight
+//     from the accumulator layout, no LDS staging.  Bias through LDS (one 1-KB DMA piece per tile, double buffered).
+// Requires M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256 (the library's large launches: M = 50432).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <utility>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#define DEV static __device__ __forceinline__
+
+template <int... I, class F>
+DEV void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+DEV void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// 1 KB per wave-instruction, global -> LDS; uniform 64-bit base + 32-bit lane offset; LDS address in M0
+DEV void dma16(const void* base_uniform, uint32_t lane_off, uint32_t lds_addr) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base_uniform), "{m0}"(lds_addr) : "memory");
+}
+
+struct G8 {
+  const bf16_t* A;
+  const bf16_t* W;
+  const float* bias;
+  bf16_t* C;
+  int M, N, K;
+  int tn, ntiles;
+  int dbg;  // diagnostics: 1 = no output stores, 2 = A row panels folded onto 8 (operand L2-resident), 4 = no bias / epilogue arithmetic either
+};
+
+constexpr int BUFB = 65536;      // one K-tile buffer: A0 | A1 | W0 | W1, 16 KB each
+constexpr int HALFB = 16384;
+constexpr int LDS_BIAS = 2 * BUFB;  // 2 x 1 KB
+constexpr int LDS_TOTAL = 2 * BUFB + 2048;
+
+__global__ __launch_bounds__(512) void gemm8p_kernel(G8 p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 15, q = lane >> 4;
+  const uint32_t ldk = (uint32_t)p.K * 2;  // bytes per operand row
+
+  // ---- staging: lane part of the source address; rows w*8 + (lane >> 3) (+ 64 j) of a half-tile, chunk lane & 7 ----
+  const int row8 = wave * 8 + (lane >> 3);
+  const uint32_t offA = (uint32_t)row8 * ldk + (uint32_t)(((lane & 7) ^ ((row8 >> 1) & 7)) << 4);
+  const uint32_t offB = (uint32_t)row8 * ldk + (uint32_t)(((lane & 7) ^ (((row8 >> 1) & 1) | (((row8 >> 3) & 3) << 1))) << 4);
+
+  // ---- fragment read addresses (byte offsets inside a K-tile buffer) ----
+  //  A: row 16 i + r of the wave's half, chunk (4 kk + q) ^ ((row >> 1) & 7)
+  //  W: accumulator tile j of the wave's 64 columns reads row slots 32 (j >> 1) + 4 (j & 1) + 8 (r >> 2) + (r & 3):
+  //     lane (r, q) then holds columns 32 (j >> 1) + 8 q + 4 (j & 1) + e of output row r; chunk ^ (row bits 1, 3, 4)
+  uint32_t a_rd[2], b_rd[2];
+  {
+    const int sA = (r >> 1) & 7;
+    const int sB = ((r >> 1) & 1) | ((r >> 2) << 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      a_rd[kk] = lds0 + wr * HALFB + r * 128 + (((4 * kk + q) ^ sA) << 4);
+      b_rd[kk] = lds0 + 2 * HALFB + (wc >> 1) * HALFB + (wc & 1) * 8192 + (8 * (r >> 2) + (r & 3)) * 128 + (((4 * kk + q) ^ sB) << 4);
+    }
+  }
+  auto lds_read = [&](uint32_t addr) -> bf16x8 {
+    return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)addr);
+  };
+
+  // ---- tile list: workgroups of one XCD (id % 8) take neighbouring tiles (they share A row panels in that L2) ----
+  const int nwg = gridDim.x;
+  const int vid = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  auto tile_bases = [&](int L, const char*& a, const char*& w, int& m0, int& n0) {
+    const int tmi = L / p.tn, tni = L - tmi * p.tn;
+    m0 = tmi * 256;
+    n0 = tni * 256;
+    a = (const char*)p.A + (size_t)((p.dbg & 2) ? (tmi & 7) * 256 : m0) * ldk;
+    w = (const char*)p.W + (size_t)n0 * ldk;
+  };
+
+  f32x4 acc[8][4];
+  bf16x8 fa[2][4];     // [kk][m tile of the current M half]
+  bf16x8 fb[2][2];     // [kk][n tile of the current N half] (the n0 fragments are read again in a K-tile's 4th phase: 16 registers)
+
+  // stage one half-tile: kind 0 A0, 1 A1, 2 W0, 3 W1
+  auto stage = [&](auto kind_, const char* a, const char* w, int kt, int buf) {
+    constexpr int kind = decltype(kind_)::value;
+    const char* src = (kind < 2 ? a : w) + (size_t)((kind & 1) * 128) * ldk + (size_t)kt * 128;
+    const uint32_t dst = lds0 + buf * BUFB + kind * HALFB + wave * 1024;
+    dma16(src, kind < 2 ? offA : offB, dst);
+    dma16(src + (size_t)64 * ldk, kind < 2 ? offA : offB, dst + 8192);
+  };
+
+  auto read_a = [&](auto mh_, int buf) {
+    constexpr int mh = decltype(mh_)::value;
+    static_for<2>([&](auto kk) {
+      static_for<4>([&](auto i) { fa[kk][i] = lds_read(a_rd[kk] + buf * BUFB + (4 * mh + i) * 2048); });
+    });
+  };
+  auto read_b = [&](auto nh_, int buf) {
+    constexpr int nh = decltype(nh_)::value;
+    static_for<2>([&](auto kk) {
+      static_for<2>([&](auto j) { fb[kk][j] = lds_read(b_rd[kk] + buf * BUFB + nh * 4096 + j * 512); });
+    });
+  };
+  auto mfma_quadrant = [&](auto mh_, auto nh_, auto zero_) {
+    constexpr int mh = decltype(mh_)::value, nh = decltype(nh_)::value;
+    constexpr bool zero = decltype(zero_)::value;
+    __builtin_amdgcn_s_setprio(1);
+    static_for<2>([&](auto kk) {
+      static_for<4>([&](auto i) {
+        static_for<2>([&](auto j) {
+          constexpr int ii = 4 * mh + i, jj = 2 * nh + j;
+          if constexpr (zero && kk == 0)
+            acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else
+            acc[ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[ii][jj], 0, 0, 0);
+        });
+      });
+    });
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // epilogue of two m-tiles (i0, i0 + 1) of one M half, both n halves: + bias, bf16, and WHOLE-LINE stores.  A lane holds
+  // 16 B of output row r in each 32-column block (p = 0, 1); lanes r and r ^ 8 of a 16-lane row exchange one block
+  // (DPP row_ror:8) so that a store instruction covers 8 rows x 128 B instead of 16 rows x 64 B (half lines cost the CU's
+  // address path ~3x per byte: qkv 188 us with half-line stores against 133 us with none).
+  auto epi_tiles = [&](auto mh_, auto i0_, int m0, int n0, int par) {
+    constexpr int mh = decltype(mh_)::value, i0 = decltype(i0_)::value;
+    const uint32_t baddr = lds0 + LDS_BIAS + par * 1024 + (wc * 64 + 8 * q) * 4;
+    f32x4 bz[4];
+    static_for<4>([&](auto t) {
+      bz[t] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)(baddr + (t >> 1) * 128 + (t & 1) * 16));
+    });
+    const bool lower = (r & 8) == 0;
+    bf16_t* crow = p.C + (size_t)(m0 + wr * 128 + 64 * mh + (r & 7)) * p.N + n0 + wc * 64 + (lower ? 0 : 32) + 8 * q;
+    static_for<2>([&](auto di) {
+      constexpr int i = i0 + di, ii = 4 * mh + i;
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = (bf16_t)(acc[ii][0][e] + bz[0][e]);
+        o0[4 + e] = (bf16_t)(acc[ii][1][e] + bz[1][e]);
+        o1[e] = (bf16_t)(acc[ii][2][e] + bz[2][e]);
+        o1[4 + e] = (bf16_t)(acc[ii][3][e] + bz[3][e]);
+      }
+      const u32x4 w0 = __builtin_bit_cast(u32x4, o0), w1 = __builtin_bit_cast(u32x4, o1);
+      u32x4 da, db;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t send = lower ? w1[d] : w0[d];
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        da[d] = lower ? w0[d] : recv;  // rows 0-7 of the m-tile: own block 0 | row r-8's block 1
+        db[d] = lower ? recv : w1[d];  // rows 8-15:             row r+8's block 0 | own block 1
+      }
+      if (!(p.dbg & 1) && (!(p.dbg & 8) || ((blockIdx.x >> 3) & 7) == 0)) {
+        if (p.dbg & 16) {  // diagnostic: non-temporal stores
+          __builtin_nontemporal_store(da, reinterpret_cast<u32x4*>(crow + (size_t)(16 * i) * p.N));
+          __builtin_nontemporal_store(db, reinterpret_cast<u32x4*>(crow + (size_t)(16 * i + 8) * p.N));
+        } else {
+          *reinterpret_cast<u32x4*>(crow + (size_t)(16 * i) * p.N) = da;
+          *reinterpret_cast<u32x4*>(crow + (size_t)(16 * i + 8) * p.N) = db;
+        }
+      } else {
+        asm volatile("" ::"v"(da), "v"(db));
+      }
+    });
+  };
+  auto seg_sync_a = [&]() {  // end of a load segment: own LDS reads retired, then the rendezvous
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto seg_sync_b = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int L = vid;
+  if (L >= p.ntiles) return;
+  if (p.dbg >> 8) {  // diagnostic: start the workgroups of a CU group (slot & 3) a quarter of `dbg >> 8` microseconds apart
+    const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 3) * (p.dbg >> 8) * 25);
+    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(16);
+  }
+  const char *ca, *cw, *na, *nw_;
+  int m0, n0, nm0, nn0;
+  tile_bases(L, ca, cw, m0, n0);
+  const int nk = p.K >> 6;
+  int par = 0;
+  // bias of a tile: one 1-KB piece by wave 0 (256 floats)
+  auto stage_bias = [&](int n0_, int par_) {
+    if (wave == 0) dma16((const char*)p.bias + (size_t)n0_ * 4, (uint32_t)lane * 16, lds0 + LDS_BIAS + par_ * 1024);
+  };
+
+  // ---- prologue: K-tile 0 complete, A0 of K-tile 1 in flight ----
+  stage(std::integral_constant<int, 0>{}, ca, cw, 0, 0);
+  stage(std::integral_constant<int, 1>{}, ca, cw, 0, 0);
+  stage(std::integral_constant<int, 2>{}, ca, cw, 0, 0);
+  stage(std::integral_constant<int, 3>{}, ca, cw, 0, 0);
+  stage(std::integral_constant<int, 0>{}, ca, cw, 1, 1);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the second M half runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  bool have_prev = false;
+  int pm0 = 0, pn0 = 0;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using T = std::true_type;
+  using F = std::false_type;
+
+  // one K-tile pair (K-tiles t0 in buffer 0, t0 + 1 in buffer 1); FIRST: the tile's first pair (C = 0, the previous
+  // tile's last quadrant leaves in phase 1); LAST: the tile's last pair (quadrants leave, the DMA stream moves on to the
+  // next tile: K-tiles t0 + 2, t0 + 3 are its K-tiles 0, 1)
+  auto pair = [&](auto first_, auto last_, int t0) {
+    constexpr bool FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
+    const char* a2 = LAST ? na : ca;
+    const char* w2 = LAST ? nw_ : cw;
+    const int k2 = LAST ? 0 : t0 + 2, k3 = LAST ? 1 : t0 + 3;
+    // ---- K-tile t0, buffer 0 ----
+    // phase 1: quadrant (m0, n0)
+    read_b(I0{}, 0);
+    read_a(I0{}, 0);
+    if constexpr (FIRST) stage_bias(n0, par);
+    stage(I1{}, ca, cw, t0 + 1, 1);  // A1 and W0 of t0 + 1 (buffer 1's W halves were last read in the previous pair's phase 8)
+    stage(I2{}, ca, cw, t0 + 1, 1);
+    seg_sync_a();
+    mfma_quadrant(I0{}, I0{}, std::integral_constant<bool, FIRST>{});
+    seg_sync_b();
+    // phase 2: (m0, n1)
+    read_b(I1{}, 0);
+    stage(I3{}, ca, cw, t0 + 1, 1);  // W1 of t0 + 1
+    // the previous tile's second M half (final after its phase 8) leaves in phases 2 and 3, BEHIND this K-tile's last
+    // piece: the counted wait of phase 4 then never waits for the acknowledgement of a store
+    if constexpr (FIRST) {
+      if (have_prev) epi_tiles(I1{}, I0{}, pm0, pn0, par ^ 1);
+    }
+    seg_sync_a();
+    mfma_quadrant(I0{}, I1{}, std::integral_constant<bool, FIRST>{});
+    seg_sync_b();
+    // phase 3: (m1, n1)
+    read_a(I1{}, 0);
+    if constexpr (FIRST) {
+      if (have_prev) epi_tiles(I1{}, I2{}, pm0, pn0, par ^ 1);
+    }
+    seg_sync_a();
+    mfma_quadrant(I1{}, I1{}, std::integral_constant<bool, FIRST>{});
+    seg_sync_b();
+    // phase 4: (m1, n0)
+    read_b(I0{}, 0);
+    stage(I0{}, a2, w2, k2, 0);  // A0 of t0 + 2 (buffer 0's W halves are read until this phase: the n0 fragments again)
+    // K-tile t0 + 1 has landed (this wave's pieces; the barrier does the rest); younger: A0 of t0 + 2 and the 8 stores
+    if (FIRST && have_prev) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    seg_sync_a();
+    mfma_quadrant(I1{}, I0{}, std::integral_constant<bool, FIRST>{});
+    seg_sync_b();
+    // ---- K-tile t0 + 1, buffer 1 ----
+    // phase 5: (m0, n0)
+    read_b(I0{}, 1);
+    read_a(I0{}, 1);
+    stage(I1{}, a2, w2, k2, 0);  // A1 and W0 of t0 + 2
+    stage(I2{}, a2, w2, k2, 0);
+    seg_sync_a();
+    mfma_quadrant(I0{}, I0{}, F{});
+    seg_sync_b();
+    // phase 6: (m0, n1)
+    read_b(I1{}, 1);
+    stage(I3{}, a2, w2, k2, 0);  // W1 of t0 + 2
+    seg_sync_a();
+    mfma_quadrant(I0{}, I1{}, F{});
+    seg_sync_b();
+    // phase 7: (m1, n1)
+    read_a(I1{}, 1);
+    if constexpr (LAST) epi_tiles(I0{}, I0{}, m0, n0, par);  // first M half (final after phase 6), m-tiles 0, 1
+    seg_sync_a();
+    mfma_quadrant(I1{}, I1{}, F{});
+    seg_sync_b();
+    // phase 8: (m1, n0)
+    read_b(I0{}, 1);
+    stage(I0{}, a2, w2, k3, 1);  // A0 of t0 + 3
+    // K-tile t0 + 2 has landed: younger than its last piece are A0 of t0 + 3 (2) and, in a LAST pair, the 4 stores of
+    // phase 7
+    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (LAST) epi_tiles(I0{}, I2{}, m0, n0, par);  // ... m-tiles 2, 3
+    seg_sync_a();
+    mfma_quadrant(I1{}, I0{}, F{});
+    seg_sync_b();
+  };
+
+  for (;;) {
+    const int Ln = L + nwg;
+    const bool more = Ln < p.ntiles;
+    // (no next tile: the stream re-loads this tile's first K-tiles into buffers nobody reads again)
+    tile_bases(more ? Ln : L, na, nw_, nm0, nn0);
+    pair(T{}, F{}, 0);
+    for (int t0 = 2; t0 < nk - 2; t0 += 2) pair(F{}, F{}, t0);
+    pair(F{}, T{}, nk - 2);
+    have_prev = true;
+    pm0 = m0;
+    pn0 = n0;
+    par ^= 1;
+    if (!more) break;
+    L = Ln;
+    ca = na;
+    cw = nw_;
+    m0 = nm0;
+    n0 = nn0;
+  }
+  // the last tile's second M half; then the first M half waits for the second's extra barrier
+  epi_tiles(I1{}, I0{}, pm0, pn0, par ^ 1);
+  epi_tiles(I1{}, I2{}, pm0, pn0, par ^ 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+typedef int (*linear_fn)(const void*, const void*, const float*, const void*, const float*, void*, int64_t, int, int, int, int, void*);
+typedef int (*pack_fn)(const void*, int, int, void*, void*);
+
+static uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fff + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 50432;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 20;
+  const char* libpath = argc > 3 ? argv[3] : "vit-deep-radiomics_amd/vdr/libvdr.so";
+  linear_fn ring4 = nullptr;
+  linear_fn ring4p = nullptr;
+  pack_fn packw = nullptr;
+  if (void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL)) {
+    ring4 = (linear_fn)dlsym(h, "vdr_op_linear");
+    ring4p = (linear_fn)dlsym(h, "vdr_op_linear_packed");
+    packw = (pack_fn)dlsym(h, "vdr_op_pack_linear_weight");
+  }
+  if (!ring4) printf("(libvdr.so not loaded from %s: %s -- no ring4 column, no bitwise check)\n", libpath, dlerror());
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int ncu = prop.multiProcessorCount;
+  CK(hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+  struct Shape { const char* name; int N, K; };
+  const Shape shapes[] = {{"qkv  N2304 K768 ", 2304, 768}, {"fc1  N3072 K768 ", 3072, 768}, {"fc2  N768  K3072", 768, 3072}, {"proj N768  K768 ", 768, 768},
+                          {"sq   N4096 K4096", 4096, 4096}};
+  std::mt19937 rng(1234);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  for (const Shape& s : shapes) {
+    const int N = s.N, K = s.K;
+    const int Ms = (N == 4096) ? 4096 : M;
+    if (Ms % 256 || N % 256 || K % 128 || K < 256) { printf("%s: skipped (shape)\n", s.name); continue; }
+    std::vector<uint16_t> hA((size_t)Ms * K), hW((size_t)N * K);
+    std::vector<float> hb(N);
+    for (auto& v : hA) v = f2bf(U(rng));
+    for (auto& v : hW) v = f2bf(U(rng) * 0.05f);
+    for (auto& v : hb) v = U(rng);
+    bf16_t *dA, *dW, *dC, *dR;
+    float* db;
+    CK(hipMalloc(&dA, hA.size() * 2));
+    CK(hipMalloc(&dW, hW.size() * 2));
+    CK(hipMalloc(&dC, (size_t)Ms * N * 2));
+    CK(hipMalloc(&dR, (size_t)Ms * N * 2));
+    CK(hipMalloc(&db, N * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dC, 0xff, (size_t)Ms * N * 2));
+    G8 g{dA, dW, db, dC, Ms, N, K, N / 256, (Ms / 256) * (N / 256), 0};
+    const int grid = std::min(ncu & ~7, g.ntiles >= 8 ? (g.ntiles & ~7) : 8);
+    g.dbg = 0;
+    auto run8 = [&]() { hipLaunchKernelGGL(gemm8p_kernel, dim3(grid), dim3(512), LDS_TOTAL, 0, g); };
+    // ring4 as the forward runs it: the pair-interleaved weight layout vdr_finalize packs once
+    bf16_t* dWp = nullptr;
+    if (ring4p && packw) {
+      CK(hipMalloc(&dWp, hW.size() * 2));
+      if (packw(dW, N, K, dWp, nullptr) != 0) { printf("pack failed\n"); return 1; }
+    }
+    auto run4 = [&]() {
+      if (dWp) ring4p(dA, dWp, db, nullptr, nullptr, dR, Ms, N, K, 0, 0, nullptr);
+      else if (ring4) ring4(dA, dW, db, nullptr, nullptr, dR, Ms, N, K, 0, 0, nullptr);
+    };
+    run8();
+    run4();
+    CK(hipDeviceSynchronize());
+    // ---- correctness: against ring4 bitwise (same MFMA, same k order) and against a float64 host sum on sampled elements
+    std::vector<uint16_t> hC((size_t)Ms * N), hR;
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
+    size_t diff = 0;
+    if (ring4) {
+      hR.resize(hC.size());
+      CK(hipMemcpy(hR.data(), dR, hR.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < hC.size(); ++i) diff += hC[i] != hR[i];
+    }
+    double maxerr = 0;
+    for (int t = 0; t < 4096; ++t) {
+      const int m = (int)(rng() % Ms), n = (int)(rng() % N);
+      double acc = hb[n];
+      for (int k = 0; k < K; ++k) acc += (double)bf2f(hA[(size_t)m * K + k]) * bf2f(hW[(size_t)n * K + k]);
+      const double got = bf2f(hC[(size_t)m * N + n]);
+      maxerr = std::max(maxerr, std::fabs(got - acc) / (std::fabs(acc) + 1.0));
+    }
+    // ---- timing: interleaved rounds of NB back-to-back launches per event pair (a lone launch between two event
+    // records reads 10-25 % long: submission gaps and the clock ramp), order alternating
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<float> t8, t4;
+    constexpr int NB = 10;
+    for (int rd = 0; rd < rounds; ++rd) {
+      for (int which = 0; which < 2; ++which) {
+        const bool first8 = (rd & 1) == 0;
+        const bool is8 = (which == 0) == first8;
+        if (!is8 && !ring4) continue;
+        CK(hipEventRecord(e0));
+        for (int b = 0; b < NB; ++b) { if (is8) run8(); else run4(); }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        (is8 ? t8 : t4).push_back(ms * 1e3f / NB);
+      }
+    }
+    auto med = [](std::vector<float> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.f : v[v.size() / 2]; };
+    auto mn = [](const std::vector<float>& v) { return v.empty() ? 0.f : *std::min_element(v.begin(), v.end()); };
+    const double gf = 2.0 * Ms * N * (double)K;
+    printf("%s M %d: 8-phase %7.1f us (min %7.1f) %6.0f TF/s | ring4 %7.1f us (min %7.1f) %6.0f TF/s | ratio %.3f | bitwise-vs-ring4 diffs %zu | max rel err vs f64 %.2e | grid %d\n",
+           s.name, Ms, med(t8), mn(t8), gf / med(t8) / 1e6, med(t4), mn(t4), ring4 ? gf / med(t4) / 1e6 : 0.0, ring4 ? med(t8) / med(t4) : 0.0, diff, maxerr, grid);
+    for (int dbg : {1, 8, 16, 8 << 8}) {
+      g.dbg = dbg;
+      std::vector<float> td;
+      for (int rd = 0; rd < 5; ++rd) {
+        CK(hipEventRecord(e0));
+        for (int b = 0; b < NB; ++b) run8();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        td.push_back(ms * 1e3f / NB);
+      }
+      printf("      dbg %5d (%s): %7.1f us\n", dbg, dbg == 1 ? "no stores" : dbg == 8 ? "1 workgroup in 8 stores" : dbg == 16 ? "non-temporal stores" : "start staggered over dbg>>8 us", med(td));
+    }
+    g.dbg = 0;
+    fflush(stdout);
+    CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(db));
+  }
+  return 0;
+}
