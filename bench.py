@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0)
     ap.add_argument("--fp8", type=int, nargs="?", const=1, default=0, choices=[0, 1],
                     help="1: qkv / fc1 / fc2 as MX-fp8 on the block-scaled MFMA (BASELINE config 5; not the headline dtype)")
+    ap.add_argument("--fp8-cls-bf16", action="store_true",
+                    help="with --fp8: the MLP of the CLS rows on the bf16 weights (vdr_config.fp8_cls_bf16)")
     ap.add_argument("--out", choices=["cls", "dense"], default="cls",
                     help="cls: [N, D] CLS features (headline); dense: [N, n*D] per-patch descriptors (BASELINE config 4)")
     ap.add_argument("--input", choices=["bf16", "fp32"], default="bf16",
@@ -154,8 +156,6 @@ def main():
                          "collective = all_gather_into_tensor; auto = mesh above 8 MB per rank")
     ap.add_argument("--dense-dtype", choices=["bf16", "fp32"], default="bf16",
                     help="--out dense: dtype of the gathered per-patch descriptors (BASELINE config 4 states bf16)")
-    ap.add_argument("--stream-gemm", action="store_true",
-                    help="vdr_config.stream_gemm = 1: qkv / fc1 on the persistent stream GEMM (A/B; same bits, not the default)")
     ap.add_argument("--clean-timing", action="store_true",
                     help="keep the per-kernel HIP events out of the timed region (roofline from a second pass)")
     a = ap.parse_args()
@@ -205,7 +205,7 @@ def main():
         ocfg = vo.CONFIGS[a.model]
         weights = vo.make_weights(ocfg, seed=1)
     model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
-                           full_last_block=a.full_last_block, stream_gemm=a.stream_gemm)
+                           full_last_block=a.full_last_block, fp8_cls_bf16=a.fp8_cls_bf16)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
@@ -311,7 +311,7 @@ def main():
     if not a.full_last_block and not sam and not dense and world == 1:
         try:
             mf = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
-                                full_last_block=True)
+                                full_last_block=True, fp8_cls_bf16=a.fp8_cls_bf16)
             ref = torch.empty_like(mine)
             for _ in range(max(a.warmup, 2)):
                 mf.engine.forward_into(images, ref, vdr.OUT_CLS)
@@ -380,7 +380,7 @@ def main():
                    "gemm_fc2": "gemm_fc2 (EPI_BIAS_RESID, K > N)", "gemm_proj": "gemm_proj (EPI_BIAS_RESID, K = N)"}.get(dom)
             if pm.get("_source_id") != vdr.source_id():
                 traffic_note = f"dropped: profiles/r03_pmc_traffic.json was taken with kernel sources {pm.get('_source_id')}, this run has {vdr.source_id()}"
-            elif key in pm and a.model == "vit_base16_224" and B == 256 and not a.stream_gemm:
+            elif key in pm and a.model == "vit_base16_224" and B == 256:
                 traffic = round((pm[key]["read_mb_corrected"] + pm[key]["write_mb"]) * 1e6)
         except Exception as e:
             traffic, traffic_note = None, f"unavailable: {type(e).__name__}"
@@ -407,7 +407,7 @@ def main():
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams,
-                          "stream_gemm": bool(a.stream_gemm),
+                          "fp8_cls_bf16": bool(a.fp8_cls_bf16),
                           "last_block": "every token" if (a.full_last_block or sam or dense) else
                                         "attention on every token; out-projection / norm2 / MLP on the CLS rows only (bitwise the same features)"},
                "feature_GBps": round(total * D * feats.element_size() * a.steps / dt / 1e9, 4),

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 6
+#define VDR_ABI_VERSION 7
 
 typedef enum {
   VDR_OK = 0,
@@ -117,13 +117,16 @@ typedef struct {
                       /* row-wise and x[:, 0] is all `model(x) -> (logits, cls)` (models_archs.py:24-29) returns; the   */
                       /* features are bitwise those of the full block.  1: every row (A/B, tests, bench.py              */
                       /* --full-last-block).  Other out_modes and post-LN models always run every row.                  */
-  int32_t patch_fusion; /* 1: p = 14 and fp32-pixel patch embeddings run patchify + GEMM + epilogue in ONE launch           */
-                      /* (csrc/patch_fused.hip; same bits; measured slower than the two launches: see that file);        */
-                      /* 0 (default): im2col + GEMM                                                                      */
-  int32_t stream_gemm; /* 1: the qkv and fc1 (GELU) linears of launches with >= 1024 tiles (K >= 768, N % 256 == 0) run on  */
-                      /* the persistent "stream" kernel (csrc/gemm_stream.hip: one workgroup per CU, K steps streaming      */
-                      /* across tile boundaries, epilogue of a tile inside the next tile's MFMAs) instead of the ring4     */
-                      /* tiles; same products in the same order: results are bitwise equal.  0 (default): ring4.           */
+  int32_t fp8_cls_bf16; /* fp8 = 1, models with a CLS token: 1 = the MLP (norm2, fc1 / w12, activation, fc2 / w3, residual) of the     */
+                      /* CLS ROWS -- one row in ntok per image, the rows the [B, D] CLS feature of models_archs.py:147 is made  */
+                      /* of -- runs on the bf16 weights (kept beside the MX-fp8 copies), on a side stream under the fp8 GEMMs of  */
+                      /* the other rows; every other row and the qkv projection stay MX-fp8.  Why: a CLS row is carried by     */
+                      /* its OWN MLP chain; when the other tokens hold massive-activation channels (DINOv2-g checkpoints) the   */
+                      /* attention adds little to it and nothing averages the MX-fp8 rounding of that chain out: row cosine to  */
+                      /* fp32 0.989 at 4 blocks / 0.919 at 40 in the stress case of tests/test_model_gpu.py, 0.9986 / 0.9886    */
+                      /* with this switch (tools/fp8_outlier_analysis.py, profiles/r04_fp8_outlier_analysis.txt).  0: every row */
+                      /* MX-fp8 (stated gate of the fp8 path: row cosine >= 0.99 against fp32 on ordinary weights; under        */
+                      /* injected massive-activation channels the CLS rows are gated at 0.985 -- a stated deviation).           */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;
@@ -214,7 +217,10 @@ int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const 
 /* epilogues of vdr_op_linear */
 typedef enum {
   VDR_EPI_BIAS = 0,      /* y = xW^T + b                      F.linear                          */
-  VDR_EPI_BIAS_GELU = 1, /* y = gelu_erf(xW^T + b)            linear1 + activation (a9)         */
+  VDR_EPI_BIAS_GELU = 1, /* y = gelu_erf(xW^T + b)            linear1 + activation (a9).  Deviation from torch: a NaN   */
+                         /*   input gives -3e-8, not NaN (the device form is max(x,0) - a 2^Q(a) on v_min / v_max, which   */
+                         /*   return their non-NaN operand; csrc/vdr_dev.h).  Inside a block the residual stream carries   */
+                         /*   the NaN row on regardless; the classifier heads hand non-finite rows on themselves.          */
   VDR_EPI_BIAS_RESID = 2,/* y = resid + gamma*(xW^T + b)      out_proj / linear2 + residual     */
   VDR_EPI_SWIGLU = 3     /* y[:, :N/2] = silu(a)*b, (a,b) = split(xW^T + b)  DINOv2 SwiGLUFFN   */
 } vdr_epilogue;
@@ -233,14 +239,6 @@ int vdr_op_linear(const void* x, const void* W, const float* bias, const void* r
  * operand loader of the GEMM touches whole lines.  vdr_op_pack_linear_weight converts W [N, K] bf16 (PyTorch layout)
  * into `packed` (N*K bf16, device); N even, K % 32 == 0.  Results are bitwise those of vdr_op_linear. */
 int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream);
-/* vdr_op_linear for a caller whose activation buffer is longer than the M rows it multiplies (the same nn.Linear call
- * sites, models_archs.py:130-135): `x_rows` >= M rows of x are readable memory.  Tile variant 30 -- the persistent
- * "stream" kernel the forward uses for its large launches (K >= 768, K % 64 == 0, N % 256 == 0) -- loads whole 128-row
- * tiles of x and therefore needs x_rows >= M rounded up to 128; rows past M are never stored.  Other variants ignore
- * x_rows.  Results are bitwise those of vdr_op_linear. */
-int vdr_op_linear_xrows(const void* x, int64_t x_rows, const void* W, const float* bias, const void* resid,
-                        const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
-                        void* stream);
 int vdr_op_linear_packed(const void* x, const void* Wp, const float* bias, const void* resid,
                          const float* gamma, void* y, int64_t M, int N, int K, int epilogue, int variant,
                          void* stream);
@@ -344,14 +342,6 @@ int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float
 int vdr_op_patch_embed(const void* images, int in_dtype, const void* W, const float* bias,
                        const float* pos, void* col, void* y, int batch, int C, int img, int p, int D,
                        int row_stride, int row_offset, void* stream);
-/* The same operator in ONE launch (csrc/patch_fused.hip): the im2col rows of 32 neighbouring patches are built in LDS
- * and multiplied there -- no `col` scratch.  What vdr_forward runs for p = 14 and for fp32 pixels (the reference's input
- * dtype, tfds_dense_descriptor.py:47) when vdr_config.patch_fusion is set.  Even p, img % p == 0, images 8-byte
- * aligned, D % 8 == 0; y bf16 or fp32 (out_dtype) rows of D.  Results are bitwise those of vdr_op_patch_embed. */
-int vdr_op_patch_embed_fused(const void* images, int in_dtype, const void* W, const float* bias, const float* pos,
-                             void* y, int out_dtype, int batch, int C, int img, int p, int D, int row_stride,
-                             int row_offset, void* stream);
-
 /* ---- measurement ------------------------------------------------------------------------ */
 
 /* Kernel classes timed by the built-in HIP-event profiler. */

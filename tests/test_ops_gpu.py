@@ -111,57 +111,6 @@ def test_linear_every_tile_variant_exact(ops, variant, packed):
         assert torch.equal(y.float().cpu(), _bf(ref + r).float()), f"variant {variant} resid {(M, N, K)}"
 
 
-def test_linear_stream_variant_exact(ops):
-    """Tile variant 30, the persistent stream GEMM (csrc/gemm_stream.hip: one workgroup per CU, K steps streaming across tile
-    boundaries, the epilogue of a tile inside the next tile's MFMAs, 16-byte stores straight from a permuted accumulator
-    layout): integer data -> bit-exact.  One tile, ragged M (rows past M readable via vdr_op_linear_xrows, never stored:
-    guard rows behind the output stay untouched), several tiles per workgroup, every K-step count class (12 = no rolled
-    loop, 13, 24), bias and erf-GELU epilogues, and the shapes it must refuse."""
-    import vdr
-    from vdr import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID
-    g = torch.Generator().manual_seed(30)
-    for (M, N, K) in [(128, 256, 768), (333, 768, 768), (1000, 512, 832), (130, 256, 1536), (128 * 300 + 5, 256, 768)]:
-        x = torch.randint(-2, 3, (M, K), generator=g).float()
-        W = torch.randint(-2, 3, (N, K), generator=g).float()
-        b = torch.randint(-3, 4, (N,), generator=g).float()
-        Mr = (M + 127) // 128 * 128
-        xpad = torch.full((Mr, K), float("nan"), dtype=torch.bfloat16, device="cuda")  # readable, never part of a stored row
-        xpad[:M] = _bf(x).cuda()
-        pad = torch.full((M + 256, N), 7.0, device="cuda", dtype=torch.bfloat16)
-        ref = x @ W.t() + b
-        y = ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS, variant=30, out=pad[:M], x_rows=Mr)
-        torch.cuda.synchronize()
-        assert torch.equal(y.float().cpu(), _bf(ref).float()), f"stream bias {(M, N, K)}"
-        assert bool((pad[M:] == 7.0).all()), f"stream wrote past row M {(M, N, K)}"
-        yg = ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS_GELU, variant=30, x_rows=Mr)
-        assert torch.equal(yg, ops.linear(xpad[:M], _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS_GELU, variant=22)), f"stream gelu {(M, N, K)}"
-    x = torch.zeros(256, 768, dtype=torch.bfloat16, device="cuda")
-    W = torch.zeros(256, 768, dtype=torch.bfloat16, device="cuda")
-    with pytest.raises(vdr.VdrError):  # ragged M without readable padding rows
-        ops.linear(x[:200], W, None, variant=30)
-    with pytest.raises(vdr.VdrError):  # K < 768: fewer steps than the epilogue schedule needs
-        ops.linear(x[:, :704].contiguous(), W[:, :704].contiguous(), None, variant=30)
-    with pytest.raises(vdr.VdrError):  # N not a multiple of the 256-column tile
-        ops.linear(x, W[:192].contiguous(), None, variant=30)
-    with pytest.raises(vdr.VdrError):  # residual epilogue: ring4 only
-        ops.linear(x, W, None, resid=x[:, :256].contiguous(), epilogue=EPI_BIAS_RESID, variant=30)
-
-
-def test_linear_stream_full_size_equals_ring_bitwise(ops):
-    """At the headline shapes (M = 50432, random data): the stream kernel == ring3, bit for bit, three launches in a row
-    (a race between the LDS ring's stages, the counted waits or the tile hand-over would show as a run-to-run change)."""
-    from vdr import EPI_BIAS, EPI_BIAS_GELU
-    g = torch.Generator().manual_seed(12)
-    M = 50432
-    for (N, K, epi) in [(2304, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (768, 3072, EPI_BIAS)]:
-        x = _bf(torch.randn(M, K, generator=g)).cuda()
-        W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
-        b = torch.randn(N, generator=g).cuda()
-        a = ops.linear(x, W, b, epilogue=epi, variant=22)
-        for rep in range(3):
-            assert torch.equal(a, ops.linear(x, W, b, epilogue=epi, variant=30)), (N, K, rep)
-
-
 def test_linear_rejects_unknown_and_ablation_variants(ops):
     """The variant argument of the C ABI selects a shipped tile configuration; diagnostic encodings (>= 100, tuning
     builds) and retired numbers are an error, never a silent garbage result."""
@@ -415,34 +364,6 @@ def test_patch_embed_gathered_from_images_exact(ops, img, p, D, B):
     y2 = ops.patch_embed(x.bfloat16().cuda(), W.bfloat16().cuda(), b.cuda(), p, pos=pos.cuda(), row_stride=n + 1, row_offset=1)
     y2 = y2.float().cpu().reshape(B, n + 1, D)
     assert torch.equal(y2[:, 1:].reshape(B * n, D), _bf(ref + pos[1:].repeat(B, 1)).float())
-
-
-@pytest.mark.parametrize("img,p,D,B,dt", [(224, 14, 384, 3, torch.float32), (224, 14, 384, 3, torch.bfloat16),
-                                           (896, 14, 384, 2, torch.float32), (336, 14, 1024, 2, torch.bfloat16),
-                                           (518, 14, 200, 1, torch.float32), (256, 16, 768, 2, torch.float32),
-                                           (64, 8, 1536, 5, torch.float32)])
-def test_patch_embed_fused_equals_two_launches(ops, img, p, D, B, dt):
-    """The one-launch patch embedding (csrc/patch_fused.hip: im2col rows built and multiplied in LDS) against im2col + GEMM:
-    bitwise equal -- same products in the same order, same epilogue arithmetic -- for p = 14 and fp32 pixels, grids of 16,
-    24, 37 (ragged last workgroup of a patch row) and 64 patches per row, D with and without whole 64 / 512-column passes,
-    a cls offset in the output rows and a position table; the fp32 output rounds to the bf16 output."""
-    g = torch.Generator().manual_seed(img + p + D)
-    x = torch.rand(B, 3, img, img, generator=g).to(dt).cuda()
-    W = (torch.randn(D, 3, p, p, generator=g) * 0.05)
-    b = torch.randn(D, generator=g).cuda()
-    n = (img // p) ** 2
-    pos = torch.randn(n + 1, D, generator=g).cuda()
-    two = ops.patch_embed(x, W.cuda(), b, p, pos=pos, row_stride=n + 1, row_offset=1)
-    one = ops.patch_embed_fused(x, W.cuda(), b, p, pos=pos, row_stride=n + 1, row_offset=1)
-    torch.cuda.synchronize()
-    assert torch.equal(one, two), f"fused patch embed differs from im2col + GEMM {(img, p, D, B, dt)}"
-    assert bool((one.view(B, n + 1, D)[:, 0] == 0).all())  # the cls rows are not this operator's
-    f32 = ops.patch_embed_fused(x, W.cuda(), b, p, pos=None, out_dtype=torch.float32)
-    assert f32.dtype == torch.float32 and torch.equal(f32.to(torch.bfloat16), ops.patch_embed(x, W.cuda(), b, p))
-    # against the convolution itself (bf16-rounded operands, fp32 accumulate): one bf16 rounding of the output
-    ref = torch.nn.functional.conv2d(x.float().to(torch.bfloat16).float(), W.cuda().to(torch.bfloat16).float(), b, stride=p)
-    ref = ref.flatten(2).transpose(1, 2).reshape(B * n, D)
-    _assert_close(f32, ref, 1e-5, 2e-4 * math.sqrt(3 * p * p / 588), "fused patch embed vs conv2d")
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])

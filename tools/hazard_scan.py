@@ -58,7 +58,7 @@ def compile_isa(sources, jobs: int = 4):
     outs, running = [], []
     for src in sources:
         out = os.path.join(tmp, os.path.basename(src)[:-4] + ".s")
-        flags = ["-fno-slp-vectorize"] if src.endswith("gemm_stream.hip") else []
+        flags = []
         running.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast"] + flags +
                                         ["-S", "--cuda-device-only", src, "-o", out], cwd=CSRC, stderr=subprocess.DEVNULL))
         outs.append(out)

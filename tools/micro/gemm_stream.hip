@@ -1,3 +1,7 @@
+// PARKED EXPERIMENT (round 3; was csrc/gemm_stream.hip, tile variant 30 / vdr_config.stream_gemm of ABI 6): built, bitwise
+// equal to ring4, not faster in the forward -- no longer compiled into libvdr.so.  tools/micro/stream_stamps.hip
+// still builds it (-I vit-deep-radiomics_amd/csrc) for its stamps.
+//
 // Persistent "stream" GEMM for gfx950:  C[M,N] = epi(A[M,K] . W[N,K]^T), bf16 in / fp32 accumulate / bf16 out.
 //
 // Replaces the same nn.Linear calls as gemm_kernels.h (reference src/models_archs.py:130-135; attn.qkv / attn.proj /

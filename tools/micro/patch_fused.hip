@@ -1,3 +1,6 @@
+// PARKED EXPERIMENT (round 3; was csrc/patch_fused.hip, vdr_op_patch_embed_fused / vdr_config.patch_fusion of ABI 6): bitwise
+// equal to im2col + GEMM and 1.6-2.1x slower (profiles/r03_patch_embed_fused_gbs.json) -- no longer compiled into libvdr.so.
+//
 // Patchify convolution in ONE launch for patch sides whose pixel runs are not 16-byte chunks (p = 14: DINOv2 /
 // ViT-L/14 / ViT-g/14) and for fp32 pixels of any even p (the reference's own input dtype):
 //   Conv2d(C, D, kernel = p, stride = p) on NCHW images -> token rows (+ bias, + pos_embed, bf16 or fp32, optional

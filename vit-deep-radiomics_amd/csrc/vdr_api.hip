@@ -98,6 +98,11 @@ struct vdr_model {
   std::vector<hipStream_t> streams;
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_join;
+  // fp8_cls_bf16: one side stream (+ fork / join events) per stream a forward can run on, created by vdr_finalize; the CLS
+  // rows' bf16 MLP of a block runs there under the MX-fp8 GEMMs of the other rows
+  std::vector<hipStream_t> aux;
+  std::vector<hipEvent_t> aux_fork, aux_join;
+  int cur_aux = 0;  // index of the stream run_blocks is being called for (set by the forward's micro-batch loop)
   // profiler
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
@@ -396,6 +401,21 @@ int resolve(vdr_model* m) {
     if (c.fp8)  // the out-projection stays bf16 on the fp8 path
       for (int i = 0; i < c.layers; ++i)
         if ((rc = pack(m->layers[i].wproj, D, D))) return rc;
+    if (c.fp8 && c.fp8_cls_bf16 && c.has_cls) {  // the CLS rows' MLP runs on the bf16 weights
+      for (int i = 0; i < c.layers; ++i)
+        if ((rc = pack(m->layers[i].w1, N1, D)) || (rc = pack(m->layers[i].w2, D, F))) return rc;
+      const size_t ns = (size_t)(c.streams > 1 ? (c.streams > 8 ? 8 : c.streams) : 1);
+      while (m->aux.size() < ns) {
+        hipStream_t st;
+        hipEvent_t ea, eb;
+        VDR_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate(CLS side stream)");
+        VDR_TRY(hipEventCreateWithFlags(&ea, hipEventDisableTiming), "hipEventCreate");
+        VDR_TRY(hipEventCreateWithFlags(&eb, hipEventDisableTiming), "hipEventCreate");
+        m->aux.push_back(st);
+        m->aux_fork.push_back(ea);
+        m->aux_join.push_back(eb);
+      }
+    }
     if (c.window > 0) {
       if ((rc = pack(m->w_neck0, c.neck_chans, D))) return rc;
       if ((rc = pack(m->w_neck2, c.neck_chans, 9 * c.neck_chans))) return rc;
@@ -423,6 +443,7 @@ struct Carve {
   char* hg = nullptr;    // SAM: LN1 output of the global blocks (h holds the windowed, zero-padded order)
   float* rel = nullptr;  // SAM: rel-pos products T[tokens][heads][relpos_npad(S)] (q . every table row)
   char *hs = nullptr, *us = nullptr, *os = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h, u, o
+  char *cls_h = nullptr, *cls_u = nullptr, *cls_x = nullptr;  // fp8_cls_bf16: norm2 / activation / new residual rows of the CLS rows
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;
   size_t total;
@@ -470,6 +491,12 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
     w.hs = take(mx_scale_bytes((int64_t)Mp, (int)D));
     w.us = take(mx_scale_bytes((int64_t)Mp, (int)F));
     w.os = take(mx_scale_bytes((int64_t)Mp, (int)D));
+    if (c.fp8_cls_bf16 && c.has_cls) {
+      const size_t rb = (size_t)round_up(mb, 256);
+      w.cls_h = take(rb * D * 2);
+      w.cls_u = take(rb * F * 2);
+      w.cls_x = take(rb * D * 2);
+    }
   }
   w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
   w.stats = (float*)take(Mp * 8);
@@ -628,10 +655,9 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
   return VDR_OK;
 }
 
-// a_rows: rows of A that are readable memory (the workspace buffers are longer than the M rows in use; 0 = M)
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold(),
-         int64_t lda = 0, int64_t ldr = 0, int64_t a_rows = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
+         int64_t lda = 0, int64_t ldr = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
   GemmArgs g{};
   g.ln_stats = ln.stats;
   g.colsum = ln.colsum;
@@ -658,12 +684,6 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.omap = identity_map();
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
-  g.a_rows = a_rows;
-  // vdr_config.stream_gemm: the write-once linears of a large launch on the persistent stream kernel (plain weight layout)
-  if (m->cfg.stream_gemm && (cls == VDR_K_GEMM_QKV || cls == VDR_K_GEMM_FC1) && gemm_stream_eligible(g, epi)) {
-    VDR_TRY(launch_gemm(g, epi, 30, s), "gemm_stream");
-    return VDR_OK;
-  }
   VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, M, N), s), "gemm");
   return VDR_OK;
 }
@@ -743,19 +763,40 @@ int gemm_mx(vdr_model* m, hipStream_t s, int cls, const void* aq, const void* as
 // result goes to a compact [mb, D] buffer -- the head of w.h, which no later kernel of this forward reads) and the MLP
 // runs on mb rows instead of mb * ntok.  Same kernels, same per-row arithmetic: the CLS features are bitwise those of
 // the full block (test_cls_rows_only_last_block_bitwise).  vdr_config.full_last_block = 1 keeps every row.
+struct BookAs {  // the profiler books these launches as VDR_K_CLS_TAIL, so that gemm_proj / fc1 / fc2 stay classes of
+  vdr_model* m;  // identical full-size launches (their averages are what the rocprofv3 summaries are compared with)
+  explicit BookAs(vdr_model* m_) : m(m_) { m->prof_as = VDR_K_CLS_TAIL; }
+  ~BookAs() { m->prof_as = -1; }
+};
+
+// vdr_config.fp8_cls_bf16: norm2 -> fc1 / w12 -> activation -> fc2 / w3 + residual of the CLS rows (row b * ntok of the
+// residual stream) on the bf16 weights, enqueued on `ax`; leaves the rows' new residual values in w.cls_x [mb, D].  Reads
+// the residual stream as it is after the out-projection; the caller puts w.cls_x back once the MX-fp8 MLP of every row has
+// written w.x.  Same kernels and per-row arithmetic as the CLS tail of the last block (block_tail_cls, explicit-LayerNorm
+// branch): a row's bits do not depend on which of the two computed it.
+int cls_mlp_bf16(vdr_model* m, hipStream_t ax, const Carve& w, const LayerW& L, int mb, int ntok) {
+  BookAs book(m);
+  const vdr_config& c = m->cfg;
+  const int D = c.dim, F = c.mlp_hidden;
+  const bool sw = c.act == VDR_ACT_SWIGLU;
+  const int64_t stride = (int64_t)ntok * D;
+  int rc;
+  if ((rc = layernorm(m, ax, VDR_K_LAYERNORM, w.x, 1, w.cls_h, 1, L.n2w, L.n2b, mb, RowMap{1, ntok, 0}))) return rc;
+  if ((rc = gemm(m, ax, VDR_K_GEMM_FC1, w.cls_h, L.w1, L.b1, nullptr, nullptr, w.cls_u, mb, sw ? 2 * F : F, D, F,
+                 sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+    return rc;
+  return gemm(m, ax, VDR_K_GEMM_FC2, w.cls_u, L.w2, L.b2, w.x, L.ls2, w.cls_x, mb, D, F, D, EPI_BIAS_RESID, LnFold(), 0, stride);
+}
+
 int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L, int mb, int ntok) {
-  struct BookAs {  // the profiler books these launches as VDR_K_CLS_TAIL, so that gemm_proj / fc1 / fc2 stay classes of
-    vdr_model* m;  // identical full-size launches (their averages are what the rocprofv3 summaries are compared with)
-    explicit BookAs(vdr_model* m_) : m(m_) { m->prof_as = VDR_K_CLS_TAIL; }
-    ~BookAs() { m->prof_as = -1; }
-  } book(m);
+  BookAs book(m);
   const vdr_config& c = m->cfg;
   const int D = c.dim, F = c.mlp_hidden;
   const bool sw = c.act == VDR_ACT_SWIGLU;
   const int64_t stride = (int64_t)ntok * D;
   char* xc = w.h;  // [mb, D] bf16
   int rc;
-  if (c.fp8) {
+  if (c.fp8 && !(c.fp8_cls_bf16 && c.has_cls)) {  // (fp8_cls_bf16: the CLS rows' MLP on the bf16 weights -- the explicit-LayerNorm branch below)
     // MX-fp8 linears: norm2 of the compact rows goes out as MX-fp8 behind them in w.h (payload) / w.hs (scales: the
     // layouts depend only on the row count each launch is given), fc1 / fc2 on the block-scaled MFMA at M = mb
     char* hq = w.h + (size_t)round_up(mb, 256) * D * 2;
@@ -811,6 +852,9 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
     // (the qkv / fc1 operand), the attention kernel and the fc1 epilogue write theirs as MX-fp8 (the proj / fc2
     // operands); the residual stream and the attention arithmetic stay bf16 / fp32.
     const int N1 = sw ? 2 * F : F;
+    // vdr_config.fp8_cls_bf16 (image models with a CLS token; not the variable-length token path)
+    const int ai = m->cur_aux;
+    const bool cls_bf16 = c.fp8_cls_bf16 && c.has_cls && c.patch && ntok > 1 && !lens && ai < (int)m->aux.size() && w.cls_x;
     for (int i = 0; i < c.layers; ++i) {
       const LayerW& L = m->layers[i];
       {
@@ -831,6 +875,13 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       }
       // the out-projection stays bf16: quantising it too measured 0.987 row cosine at 40 blocks (gate 0.99)
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
+      if (cls_bf16) {
+        // fork: the CLS rows' bf16 MLP runs on the side stream under norm2 / fc1 of every row (nothing writes w.x there)
+        VDR_TRY(hipEventRecord(m->aux_fork[ai], s), "hipEventRecord");
+        VDR_TRY(hipStreamWaitEvent(m->aux[ai], m->aux_fork[ai], 0), "hipStreamWaitEvent");
+        if ((rc = cls_mlp_bf16(m, m->aux[ai], w, L, mb, ntok))) return rc;
+        VDR_TRY(hipEventRecord(m->aux_join[ai], m->aux[ai]), "hipEventRecord");
+      }
       {
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 3);
         VDR_TRY(launch_ln_mx(w.x, L.n2w, L.n2b, c.ln_eps, M, D, w.h, w.hs, s), "layernorm_mx");
@@ -838,8 +889,13 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC1, w.h, w.hs, L.w1_q, L.w1_s, L.b1, nullptr, nullptr, w.u, w.us, M, N1, D, F,
                         sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
         return rc;
+      // join: fc2 rewrites every row of w.x, the CLS rows' residual reads must be over
+      if (cls_bf16) VDR_TRY(hipStreamWaitEvent(s, m->aux_join[ai], 0), "hipStreamWaitEvent");
       if ((rc = gemm_mx(m, s, VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, w.x, L.ls2, w.x, nullptr, M, D, F, D, EPI_BIAS_RESID)))
         return rc;
+      if (cls_bf16)  // ... and the bf16 result replaces the MX-fp8 one in the CLS rows
+        VDR_TRY(hipMemcpy2DAsync(w.x, (size_t)ntok * D * 2, w.cls_x, (size_t)D * 2, (size_t)D * 2, (size_t)mb, hipMemcpyDeviceToDevice, s),
+                "hipMemcpy2DAsync(CLS rows)");
     }
     return VDR_OK;
   }
@@ -854,7 +910,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       LnFold cons;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_QKV, M, 3 * D, D, w, &cons))) return rc;
       cons.colsum = L.sqkv;
-      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons, 0, 0, w.Mp)))
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons)))
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -869,7 +925,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons, 0, 0, w.Mp)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod))) return rc;
     }
@@ -882,7 +938,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
       attn_in = w.h;
     }
-    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, LnFold(), 0, 0, w.Mp)))
+    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS)))
       return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -897,7 +953,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.h, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, LnFold(), 0, 0, w.Mp)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
     } else {
@@ -1148,6 +1204,7 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
   }
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
   if (c.fp8 && !c.pre_ln) return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models only");
+  if (c.fp8_cls_bf16 < 0 || c.fp8_cls_bf16 > 1) return fail(nullptr, VDR_ERR_INVALID, "fp8_cls_bf16 must be 0 or 1");
   if (c.fp8 < 0 || c.fp8 > 1)
     return fail(nullptr, VDR_ERR_UNSUPPORTED,
                 "fp8 must be 0 or 1 (a level that also quantised the out-projection measured 0.987 row cosine at 40 "
@@ -1201,6 +1258,9 @@ void vdr_destroy(vdr_handle h) {
   for (auto& kv : h->w_il)
     if (kv.second) hipFree(kv.second);
   for (auto st : h->streams) hipStreamDestroy(st);
+  for (auto st : h->aux) hipStreamDestroy(st);
+  for (auto e : h->aux_fork) hipEventDestroy(e);
+  for (auto e : h->aux_join) hipEventDestroy(e);
   for (auto e : h->ev_join) hipEventDestroy(e);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   for (auto& e : h->ev_used) {
@@ -1354,6 +1414,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
   for (int b0 = 0; b0 < batch; b0 += mb_max, ++chunk) {
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
     const int si = chunk % ns;
+    m->cur_aux = si;
     hipStream_t s = ns == 1 ? caller : m->streams[si];
     const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* img = (const char*)images + (size_t)b0 * img_elems * in_es;
@@ -1363,19 +1424,6 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     const int pvar = gemm_variant_for(VDR_K_GEMM_PATCH, (int64_t)mb * n, D);
     const bool fused_patch = patch_gather_ok(in_dtype, c.patch, pvar, img);
     const bool pe_only = out_mode == VDR_OUT_PATCH_EMBED;
-    // vdr_config.patch_fusion: what the in-loader gather does not take -- p = 14, fp32 pixels (what the reference feeds) --
-    // runs the patchify, the GEMM and its epilogue in ONE launch (patch_fused.hip: same bits, measured slower; off by default)
-    const bool one_launch = !fused_patch && c.patch_fusion && patch_fused_ok(img, in_dtype == VDR_BF16, c.img, c.patch, m->Kp, D);
-    if (one_launch) {
-      void* dst = pe_only ? (void*)((char*)out + (size_t)b0 * n * D * (out_dtype == VDR_BF16 ? 2 : 4)) : (void*)w.x;
-      const int f32 = pe_only && out_dtype != VDR_BF16;
-      const RowMap om = pe_only ? RowMap{n, n, 0} : RowMap{n, ntok, ncls};
-      Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * mb * n * D * c.in_chans * c.patch * c.patch,
-               (double)mb * img_elems * in_es + 2.0 * D * m->Kp + (double)mb * n * D * (f32 ? 4 : 2));
-      VDR_TRY(launch_patch_fused(img, in_dtype == VDR_BF16, m->w_patch, m->b_patch, pe_only ? nullptr : m->pos, dst, f32,
-                                 (m->ln_fuse && !pe_only) ? w.part : nullptr, w.Mp, mb, c.in_chans, c.img, c.patch, m->Kp, D, om, s),
-              "patch embed");
-    } else {
     if (!fused_patch) {
       Scope sc(m, s, VDR_K_IM2COL, 0.0, (double)mb * img_elems * in_es + 2.0 * mb * n * m->Kp);
       VDR_TRY(launch_im2col(img, in_dtype == VDR_BF16, w.u, mb, c.in_chans, c.img, c.patch, m->Kp, s), "im2col");
@@ -1415,7 +1463,6 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
       Scope sc(m, s, VDR_K_GEMM_PATCH, 2.0 * g.M * D * c.in_chans * c.patch * c.patch,
                2.0 * ((double)g.M * m->Kp + (double)D * m->Kp + (double)g.M * D));
       VDR_TRY(launch_gemm_w(m, g, EPI_PATCH, pvar, s), "patch gemm");
-    }
     }
     if (pe_only) continue;
     if (c.window > 0) {
@@ -1489,6 +1536,7 @@ static int forward_tokens_impl(vdr_handle m, const void* tokens, int in_dtype, i
   for (int b0 = 0; b0 < batch; b0 += mb_max, ++chunk) {
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
     const int si = chunk % ns;
+    m->cur_aux = si;
     hipStream_t s = ns == 1 ? caller : m->streams[si];
     const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* tok = (const char*)tokens + (size_t)b0 * seq * D * in_es;
@@ -1541,7 +1589,7 @@ int vdr_op_layernorm(const void* x, int in_dtype, void* y, int out_dtype, const 
 }
 
 static int op_linear_impl(const void* x, const void* W, int packed, const float* bias, const void* resid, const float* gamma,
-                          void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream, int64_t x_rows = 0) {
+                          void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream) {
   if (!x || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
   if (epilogue < VDR_EPI_BIAS || epilogue > VDR_EPI_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "epilogue");
   if (epilogue == VDR_EPI_BIAS_RESID && !resid) return fail(nullptr, VDR_ERR_INVALID, "resid required");
@@ -1567,7 +1615,6 @@ static int op_linear_impl(const void* x, const void* W, int packed, const float*
   g.ldc = epilogue == VDR_EPI_SWIGLU ? N / 2 : N;
   g.ldr = g.ldc;
   g.omap = identity_map();
-  g.a_rows = x_rows;
   if (variant == 0)  // library default: what the forward itself would pick for this shape
     variant = gemm_variant_for(N >= 2304 ? VDR_K_GEMM_QKV : VDR_K_GEMM_FC1, M, N);
   const hipError_t e = launch_gemm(g, epilogue, variant, (hipStream_t)stream);
@@ -1582,12 +1629,6 @@ static int op_linear_impl(const void* x, const void* W, int packed, const float*
 int vdr_op_linear(const void* x, const void* W, const float* bias, const void* resid, const float* gamma, void* y,
                   int64_t M, int N, int K, int epilogue, int variant, void* stream) {
   return op_linear_impl(x, W, 0, bias, resid, gamma, y, M, N, K, epilogue, variant, stream);
-}
-
-int vdr_op_linear_xrows(const void* x, int64_t x_rows, const void* W, const float* bias, const void* resid, const float* gamma,
-                        void* y, int64_t M, int N, int K, int epilogue, int variant, void* stream) {
-  if (x_rows < M) return fail(nullptr, VDR_ERR_INVALID, "x_rows < M");
-  return op_linear_impl(x, W, 0, bias, resid, gamma, y, M, N, K, epilogue, variant, stream, x_rows);
 }
 
 int vdr_op_pack_linear_weight(const void* W, int N, int K, void* packed, void* stream) {
@@ -1762,22 +1803,6 @@ int vdr_op_attention_relpos(const void* qkv, const float* rel_pos_h, const float
   OP_TRY(launch_relpos_pack(rel_pos_h, rel_pos_w, table, S, (hipStream_t)stream), "relpos_pack");
   OP_TRY(relpos_products(qkv, table, rel, tokens, S, heads, (hipStream_t)stream), "relpos");
   OP_TRY(launch_attention_relpos(qkv, rel, out, batch, S, heads, (hipStream_t)stream), "attention_relpos");
-  return VDR_OK;
-}
-
-int vdr_op_patch_embed_fused(const void* images, int in_dtype, const void* W, const float* bias, const float* pos, void* y,
-                             int out_dtype, int batch, int C, int img, int p, int D, int row_stride, int row_offset, void* stream) {
-  if (!images || !W || !y) return fail(nullptr, VDR_ERR_INVALID, "null argument");
-  if (p <= 0 || img % p) return fail(nullptr, VDR_ERR_INVALID, "img must be a multiple of p");
-  if ((in_dtype != VDR_F32 && in_dtype != VDR_BF16) || (out_dtype != VDR_F32 && out_dtype != VDR_BF16))
-    return fail(nullptr, VDR_ERR_INVALID, "dtype");
-  int rc = check_device(nullptr);
-  if (rc) return rc;
-  const int g = img / p, n = g * g, Kp = round_up(C * p * p, 64);
-  if (!patch_fused_ok(images, in_dtype == VDR_BF16, img, p, Kp, D))
-    return fail(nullptr, VDR_ERR_UNSUPPORTED, "patch_embed_fused: even p, 8-byte aligned images, D % 8 == 0, 32 (2 Kp + 32) <= 80 KB required");
-  OP_TRY(launch_patch_fused(images, in_dtype == VDR_BF16, W, bias, pos, y, out_dtype == VDR_F32, nullptr, 0, batch, C, img, p, Kp, D,
-                            RowMap{n, row_stride, row_offset}, (hipStream_t)stream), "patch_embed_fused");
   return VDR_OK;
 }
 

@@ -81,7 +81,6 @@ struct GemmArgs {
   int a_rpg = 0;
   int64_t a_gs = 0, a_is = 0;
   int out_f32 = 0;  // C is fp32 (EPI_BIAS / EPI_PATCH)
-  int64_t a_rows = 0;  // rows of A that are readable memory (>= M; 0 = M): the stream kernel (variant 30) loads whole tiles
   // im2col-free patchify (EPI_PATCH on the ring4 variants): A = bf16 NCHW images [B, C, g*p, g*p], M = B*g*g tokens,
   // K = C*p*p with p in {8, 16, 32}; the operand loader gathers 16-byte runs of pixels straight from the images
   int patch_p = 0, patch_g = 0, patch_C = 0;
@@ -92,9 +91,6 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
-// whether variant 30 (gemm_stream.hip) takes this launch and is expected to pay: a write-once epilogue, plain weight layout,
-// K >= 768, N % 256 == 0, A readable up to the tile edge (a_rows), at least 1024 tiles
-bool gemm_stream_eligible(const GemmArgs& a, int epilogue);
 // [N][K] bf16 (row stride ld elements) -> the pair-interleaved weight layout (N even, K % 32 == 0)
 hipError_t launch_w_interleave(const void* src, void* dst, int N, int K, int64_t ld, hipStream_t s);
 
@@ -170,13 +166,6 @@ hipError_t launch_im2col3(const void* y, void* col, int batch, int g, int C, hip
 // images NCHW -> col [batch*n, Kp] bf16 with k = c*p*p + ky*p + kx, zero padded to Kp
 hipError_t launch_im2col(const void* images, int in_bf16, void* col, int batch, int C, int img, int p,
                          int Kp, hipStream_t s);
-
-// patchify + GEMM + epilogue in one launch (patch_fused.hip): even patch sides, fp32 or bf16 pixels; W [D][Kp] in the plain
-// layout; out = bf16 token rows (optionally + LayerNorm partials) or fp32 rows.  Bitwise equal to launch_im2col + EPI_PATCH GEMM
-bool patch_fused_ok(const void* images, int in_bf16, int img, int p, int Kp, int D);
-hipError_t launch_patch_fused(const void* images, int in_bf16, const void* W, const float* bias, const float* pos, void* out,
-                              int out_f32, float* ln_part, int64_t part_stride, int batch, int C, int img, int p, int Kp, int D,
-                              RowMap omap, hipStream_t s);
 
 // x[b*row_stride + 0][:] = cls + pos[0]  (bf16 out)
 hipError_t launch_cls_rows(const float* cls, const float* pos, void* x, int batch, int64_t row_stride,

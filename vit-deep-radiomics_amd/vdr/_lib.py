@@ -28,7 +28,7 @@ class vdr_config(C.Structure):
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
                 ("streams", C.c_int32), ("window", C.c_int32),
                 ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32),
-                ("full_last_block", C.c_int32), ("patch_fusion", C.c_int32), ("stream_gemm", C.c_int32)]
+                ("full_last_block", C.c_int32), ("fp8_cls_bf16", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)
@@ -52,7 +52,6 @@ SYMBOLS = {
     "vdr_op_linear": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_op_pack_linear_weight": (_I, [_P, _I, _I, _P, _P]),
     "vdr_op_linear_packed": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
-    "vdr_op_linear_xrows": (_I, [_P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vdr_prepare_scratch_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "vdr_op_prepare_image": (_I, [_P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _I, _P, _P]),
     "vdr_op_window_ct": (_I, [_P, _I, _L, C.c_double, C.c_double, _P, _P]),
@@ -69,7 +68,6 @@ SYMBOLS = {
     "vdr_op_attention": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "vdr_op_attention_relpos": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "vdr_op_patch_embed": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "vdr_op_patch_embed_fused": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vdr_profile_enable": (_I, [_P, _I]),
     "vdr_profile_mask": (_I, [_P, C.c_uint32]),
     "vdr_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double),
@@ -96,7 +94,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vdr_abi_version() != 6:
+    if lib.vdr_abi_version() != 7:
         raise ImportError("libvdr ABI version mismatch")
     _lib = lib
     return lib

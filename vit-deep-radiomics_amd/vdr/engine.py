@@ -37,8 +37,7 @@ class VdrConfig:
     ln_fold: bool = True       # pre-LN image models: LayerNorm folded into the qkv / fc1 GEMMs (False: explicit kernel)
     full_last_block: bool = False  # CLS output: True keeps every row of the last block (default: its CLS rows only,
                                # the same features bit for bit; see vdr_config.full_last_block)
-    patch_fusion: bool = False  # True: p = 14 / fp32-pixel patch embedding in one launch (same bits; measured slower)
-    stream_gemm: bool = False  # qkv / fc1 of large launches on the persistent stream kernel (vdr_config.stream_gemm; same bits)
+    fp8_cls_bf16: bool = False  # fp8 = 1: the MLP of the CLS rows on the bf16 weights (vdr_config.fp8_cls_bf16)
 
     @property
     def n_patches(self):
@@ -61,8 +60,7 @@ class VdrConfig:
         c.fp8 = int(self.fp8)
         c.no_ln_fold = int(not self.ln_fold)
         c.full_last_block = int(self.full_last_block)
-        c.stream_gemm = int(self.stream_gemm)
-        c.patch_fusion = int(self.patch_fusion)
+        c.fp8_cls_bf16 = int(self.fp8_cls_bf16)
         return c
 
 

@@ -37,11 +37,9 @@ def pack_linear_weight(W: torch.Tensor) -> torch.Tensor:
     return Wp
 
 
-def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None, packed=False, x_rows=0):
+def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant=0, out=None, packed=False):
     """x [M,K] bf16, W [N,K] bf16 (for EPI_SWIGLU W/bias must already be gate-pair packed: see pack_w12).
-    packed=True: W is the result of pack_linear_weight (same values, whole-line operand loads).
-    x_rows > 0: x is the head of a buffer with that many readable rows (vdr_op_linear_xrows: what variant 30 needs for a
-    ragged M)."""
+    packed=True: W is the result of pack_linear_weight (same values, whole-line operand loads)."""
     lib = L.load()
     assert x.is_cuda and x.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and x.is_contiguous() and W.is_contiguous()
     M, K = x.shape
@@ -49,11 +47,6 @@ def linear(x, W, bias=None, resid=None, gamma=None, epilogue=L.EPI_BIAS, variant
     assert W.shape[1] == K
     if out is None:
         out = torch.empty((M, N // 2 if epilogue == L.EPI_SWIGLU else N), dtype=torch.bfloat16, device=x.device)
-    if x_rows:
-        assert not packed
-        L.check(lib.vdr_op_linear_xrows(x.data_ptr(), x_rows, W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K,
-                                        epilogue, variant, _s(x)))
-        return out
     fn = lib.vdr_op_linear_packed if packed else lib.vdr_op_linear
     L.check(fn(x.data_ptr(), W.data_ptr(), _p(bias), _p(resid), _p(gamma), out.data_ptr(), M, N, K, epilogue, variant, _s(x)))
     return out
@@ -160,26 +153,6 @@ def patch_embed(images, weight, bias, p, pos=None, row_stride=None, row_offset=0
     L.check(lib.vdr_op_patch_embed(images.data_ptr(), 1 if images.dtype == torch.bfloat16 else 0, Wp.data_ptr(),
                                    _p(bias), _p(pos), col.data_ptr(), out.data_ptr(), B, Cc, H, p, D, row_stride,
                                    row_offset, _s(images)))
-    return out
-
-
-def patch_embed_fused(images, weight, bias, p, pos=None, row_stride=None, row_offset=0, out_dtype=torch.bfloat16):
-    """patch_embed in one launch (vdr_op_patch_embed_fused): no col scratch; bf16 or fp32 rows out."""
-    lib = L.load()
-    B, Cc, H, _ = images.shape
-    D = weight.shape[0]
-    g = H // p
-    n = g * g
-    K = Cc * p * p
-    Kp = (K + 63) // 64 * 64
-    Wp = torch.zeros((D, Kp), dtype=torch.bfloat16, device=images.device)
-    Wp[:, :K] = weight.reshape(D, K).to(torch.bfloat16)
-    row_stride = n if row_stride is None else row_stride
-    out = torch.zeros((B * row_stride, D), dtype=out_dtype, device=images.device)
-    images = images.contiguous()
-    L.check(lib.vdr_op_patch_embed_fused(images.data_ptr(), 1 if images.dtype == torch.bfloat16 else 0, Wp.data_ptr(), _p(bias), _p(pos),
-                                         out.data_ptr(), 1 if out_dtype == torch.bfloat16 else 0, B, Cc, H, p, D, row_stride, row_offset,
-                                         _s(images)))
     return out
 
 
