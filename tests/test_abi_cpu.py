@@ -94,3 +94,24 @@ def test_no_wide_buffer_store_is_followed_by_a_write_of_its_data():
         total += n
         assert not hits, hits[:3]
     assert total > 0  # the scan saw the stores it is about
+
+
+def test_no_asm_memory_instruction_reads_an_sgpr_a_valu_has_just_written():
+    """The cause of round 3's ring4d memory-access faults (tools/micro/gemm_ring4d_experiment.hip, header): hipcc inserts no
+    hazard wait states INSIDE an asm statement, and `VALU writes SGPR -> vector-memory instruction reads it` needs 5 -- a
+    pointer reloaded from an SGPR spill (v_readlane) right ahead of an opaque atomic gave it a stale base address.  Every
+    kernel of the library that issues memory instructions from asm statements (the opaque LDS-DMA of the attention kernels)
+    is compiled to ISA and scanned for that pattern."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(ROOT, "tools", "hazard_scan.py"))
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    srcs = [f for f in sorted(glob.glob(os.path.join(hs.CSRC, "*.hip"))) if "glds16_raw" in open(f).read() or "asm volatile(\"global_" in open(f).read()]
+    assert srcs
+    total = 0
+    for s in hs.compile_isa(srcs, jobs=4):
+        n, hits = hs.scan_asm_sgpr(s)
+        total += n
+        assert not hits, hits[:3]
+    assert total > 0

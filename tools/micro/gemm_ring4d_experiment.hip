@@ -20,9 +20,23 @@
 //     registers so that the scheduler cannot move the write in front of it; tools/hazard_scan.py looks for the
 //     pattern in the library's ISA (none: the shipped stores with an SGPR soffset are followed by other stores or the end).
 //   * with the draw as an opaque `global_atomic_add v127 ... sc0` (v127 kept out of hipcc's hands by amdgpu_num_vgpr(127))
-//     the kernel raises a memory access fault on its first multi-tile launch, with or without wait states behind the
-//     instruction; with atomicAdd it does not.  The builtin costs thread 0's wave a vmcnt(0) right behind the draw (hipcc's
-//     atomic optimizer reads the result back at once), i.e. that wave's fill is not overlapped;
+//     the kernel raised a memory access fault on its first multi-tile launch (gpurun_out/r3/r4d_{2,3,8}.log); with atomicAdd
+//     it does not.  CAUSE (round 4, from the ISA of that build -- commit 6cc6aa2 with R4D_BUILTIN_DRAW undefined, hipcc -S --
+//     not from re-running it): NOT v127 -- the kernel descriptors read .amdhsa_next_free_vgpr 128, .amdhsa_accum_offset 128,
+//     .agpr_count 0, so v127 is the last architected VGPR of the wave's allocation.  It is the atomic's BASE ADDRESS.  At its
+//     128-register budget the persistent loop spills SGPRs to lanes of v126, and the in-loop draw compiles to
+//         v_readlane_b32 s78, v126, 4 / v_readlane_b32 s79, v126, 5 / v_mov_b32 v0, s30 / v_mov_b32 v102, 1
+//         ;;#ASMSTART  global_atomic_add v127, v0, v102, s[78:79] sc0  ;;#ASMEND
+//     `VALU writes an SGPR -> a vector-memory instruction reads that SGPR` needs 5 wait states on gfx9 / CDNA and hipcc's
+//     hazard recognizer does not look INSIDE an asm statement: with 2-3 wait states the atomic went to whatever s[78:79]
+//     held before (scalar temporaries of the tile-index divisions) -- a wild address, on the first launch whose loop runs
+//     (the one-tile integer cases only execute the prologue draw, whose pointer pair comes straight from s_load).  Wait states
+//     BEHIND the instruction, which is what was tried, cannot help; `s_nop 4` as the first line of the asm statement (or the
+//     pointer handed over as a VGPR pair) does.  An "=v" output instead of v127 would not have.  tools/hazard_scan.py now
+//     flags the pattern (6 of the 8 asm atomics of that build) and tests/test_abi_cpu.py keeps the library's own asm memory
+//     instructions (the opaque LDS-DMA of the attention kernels: 180, none behind a VALU write of their SGPRs) clean.
+//     The builtin costs thread 0's wave a vmcnt(0) right behind the draw (hipcc's atomic optimizer reads the result back at
+//     once), i.e. that wave's fill is not overlapped;
 //   * the launcher once asked for 80 KB + 16 B of LDS: one workgroup per CU instead of two, 215 / 306 / 260 us.
 //
 // ring4d: the ring4 main loop (gemm_kernels.h: 128 x 256 tile, 8 waves, two workgroups per CU) as PERSISTENT workgroups
