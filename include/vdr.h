@@ -127,6 +127,14 @@ typedef struct {
                       /* with this switch (tools/fp8_outlier_analysis.py, profiles/r04_fp8_outlier_analysis.txt).  0: every row */
                       /* MX-fp8 (stated gate of the fp8 path: row cosine >= 0.99 against fp32 on ordinary weights; under        */
                       /* injected massive-activation channels the CLS rows are gated at 0.985 -- a stated deviation).           */
+  int32_t resid_fp32; /* 1 (bf16 path of pre-LN image models; ignored with fp8 = 1, SAM windows and token models): the residual    */
+                      /* stream has an fp32 master copy -- the out-projection / fc2 epilogues read it, add in fp32, write it back */
+                      /* and write the bf16 copy the next GEMM multiplies; LayerNorm and the final norm read the fp32 copy.  The  */
+                      /* reference computes in fp32 throughout (tfds_dense_descriptor.py:123); with the stream stored as bf16      */
+                      /* (0, default) its rounding accumulates over the blocks: rel-L2 of the features to fp32 arithmetic 9e-3 /     */
+                      /* 1.2e-2 / 1.7e-2 at 12 / 24 / 40 blocks, against 5.8e-3 / 6.6e-3 / 1.0e-2 with this switch                 */
+                      /* (tools/resid_precision.py; SURVEY 8d states 1e-2).  Costs 8 more bytes per element of HBM traffic in     */
+                      /* the out-projection and fc2 launches.                                                                     */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

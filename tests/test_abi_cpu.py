@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from vdr import _lib
-    assert C.sizeof(_lib.vdr_config) == 4 * 23  # 22 int32 fields + one float
+    assert C.sizeof(_lib.vdr_config) == 4 * 24  # 23 int32 fields + one float
 
 
 def test_invalid_configs_are_rejected_before_touching_a_device():

@@ -36,13 +36,13 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True, full_last_block=False, fp8_cls_bf16=False):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True, full_last_block=False, fp8_cls_bf16=False, resid_fp32=False):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
                        has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
                        micro_batch=micro_batch, fp8=fp8, ln_fold=ln_fold, full_last_block=full_last_block,
-                       fp8_cls_bf16=fp8_cls_bf16)
+                       fp8_cls_bf16=fp8_cls_bf16, resid_fp32=resid_fp32)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -833,3 +833,39 @@ def test_golden_reference_bimodal_classifier(golden_dir, tag):
         m(None, None)
     # single-modality mode returns the encoder's CLS row: identical to the unimodal engine path
     assert torch.equal(m(x_ct, None)[1], m.engines["ct"].forward_tokens(x_ct, vdr.OUT_CLS))
+
+
+@pytest.mark.parametrize("name", ["p16_d128", "p14_d192", "dinov2_swiglu_ls"])
+@pytest.mark.parametrize("ln_fold", [True, False])
+def test_resid_fp32_master_copy_of_the_residual_stream(name, ln_fold):
+    """vdr_config.resid_fp32: the out-projection / fc2 epilogues keep an fp32 master copy of the residual stream (the
+    reference computes in fp32 throughout, tfds_dense_descriptor.py:123); LayerNorm / the final norm read it, the next GEMM
+    multiplies its bf16 rounding.  (i) closer to the fp32 oracle than the bf16 stream, and as close to the emulating oracle
+    run with vo.RESID_FP32 as the bf16 path is to its emulation; (ii) the CLS tail of the last block stays bitwise the full
+    block; (iii) micro-batches do not change a row."""
+    import vdr
+    cfg = SMALL[name]
+    w = vo.make_weights(cfg, seed=61, scale=0.05)
+    x = vo.make_images(cfg, 5, seed=62)
+    ref = vo.forward_images(cfg, w, x)
+    vo.RESID_FP32 = True
+    try:
+        emu = vo.forward_images(cfg, w, x, emulate_bf16=True)
+    finally:
+        vo.RESID_FP32 = False
+    e32 = _engine(cfg, w, ln_fold=ln_fold, resid_fp32=True)
+    e16 = _engine(cfg, w, ln_fold=ln_fold)
+    tok32 = e32.forward(x.cuda(), vdr.OUT_TOKENS).float().cpu()
+    tok16 = e16.forward(x.cuda(), vdr.OUT_TOKENS).float().cpu()
+    r32, r16, remu = _rel_l2(tok32, ref["tokens"]), _rel_l2(tok16, ref["tokens"]), _rel_l2(tok32, emu["tokens"])
+    print(f"{name} fold={ln_fold}: relL2 vs fp32 oracle: bf16 stream {r16:.3e}, fp32 stream {r32:.3e}; fp32 stream vs its emulation {remu:.3e}")
+    assert torch.isfinite(tok32).all() and not torch.equal(tok32, tok16)
+    assert r32 <= gate_l2(cfg.layers) and r32 <= 1.05 * r16 and _min_cos(tok32, ref["tokens"]) >= 0.999
+    assert remu <= gate_l2(cfg.layers)
+    full = _engine(cfg, w, ln_fold=ln_fold, resid_fp32=True, full_last_block=True)
+    ref_cls = full.forward(x.cuda(), vdr.OUT_CLS)
+    assert torch.equal(ref_cls, full.forward(x.cuda(), vdr.OUT_TOKENS)[:, 0])
+    for mb in (0, 2):
+        got = _engine(cfg, w, ln_fold=ln_fold, resid_fp32=True, micro_batch=mb).forward(x.cuda(), vdr.OUT_CLS)
+        assert torch.equal(got, ref_cls), f"micro_batch {mb}"
+    assert torch.equal(e32.forward(x.cuda(), vdr.OUT_DENSE), full.forward(x.cuda(), vdr.OUT_DENSE))

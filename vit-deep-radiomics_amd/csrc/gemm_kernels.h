@@ -703,6 +703,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(G
       VDR_GLOBAL(W);
       VDR_GLOBAL(bias);
       VDR_GLOBAL(resid);
+      VDR_GLOBAL(resid32);
+      VDR_GLOBAL(C32);
       VDR_GLOBAL(gamma);
       VDR_GLOBAL(pos);
       VDR_GLOBAL(C);
@@ -747,7 +749,7 @@ static auto launch_pick_persistent() -> void (*)(GemmK) {
 #ifdef VDR_TUNING
   if constexpr (PIPE >= 50) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E, TAG>;
 #else
-  if constexpr (PIPE >= 50 && E == EPI_BIAS_RESID) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E, TAG>;
+  if constexpr (PIPE >= 50 && epi_base(E) == EPI_BIAS_RESID) return gemm_ring4p_kernel<WAVES_M, WAVES_N, E, TAG>;
 #endif
   return launch_pick<WAVES_M, WAVES_N, PIPE, E, TAG>();
 }
@@ -777,6 +779,12 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.w_il = a.w_interleaved;
   k.bias = a.bias;
   k.resid = (const bf16_t*)a.resid;
+  k.resid32 = a.resid32;
+  k.C32 = a.C32;
+  if (a.resid32 || a.C32) {  // the fp32 residual stream: its own instantiation of the residual kernels
+    if (epi != EPI_BIAS_RESID || !a.resid32 || !a.C32 || a.win_ws || (PIPE >= 40 && PIPE < 50)) return hipErrorInvalidValue;
+    epi = EPI_BIAS_RESID32;
+  }
   k.gamma = a.gamma;
   k.pos = a.pos;
   k.C = (bf16_t*)a.C;
@@ -841,7 +849,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.ln_fold = a.ln_stats || a.ln_cpart;
   if (a.ldc >= ((int64_t)1 << 24)) return hipErrorInvalidValue;  // (epilogue_bf16 addresses a wave tile with 32-bit byte offsets)
   // (the residual epilogue, epilogue_resid: bf16 in place or out of place, no consumer-side fold, 32-bit row numbers)
-  if (epi == EPI_BIAS_RESID && (k.ln_fold || a.out_f32 || a.M >= ((int64_t)1 << 31))) return hipErrorInvalidValue;
+  if (epi_base(epi) == EPI_BIAS_RESID && (k.ln_fold || a.out_f32 || a.M >= ((int64_t)1 << 31))) return hipErrorInvalidValue;
   if (a.ln_cpart) {
     if ((PIPE >= 40 && PIPE < 50) || a.ln_groups < 1 || a.ln_groups > 16 || a.ln_stats) return hipErrorInvalidValue;
     k.ln_cpart = a.ln_cpart;
@@ -859,7 +867,7 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   dim3 grid((unsigned)k.nwg), block(NWV * 64);
   const int dev = current_device_index();
   if (dev < 0) return hipErrorInvalidDevice;
-  bool persistent = PIPE >= 50 && epi == EPI_BIAS_RESID;  // (see gemm_ring4p_kernel)
+  bool persistent = PIPE >= 50 && epi_base(epi) == EPI_BIAS_RESID;  // (see gemm_ring4p_kernel)
 #ifdef VDR_TUNING
   {
     VDR_KNOB int pers_env = tuning_env("VDR_GEMM_PERSISTENT", -1);
@@ -927,11 +935,13 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
     break;                                                                                             \
   }
   // (the residual GEMM with K > N -- fc2 -- launches the TAG 1 symbol of the same code: profiles tell it from the out-projection)
-  switch (epi + (PIPE >= 50 && epi == EPI_BIAS_RESID && a.K > a.N ? 100 : 0)) {
+  switch (epi + (PIPE >= 50 && epi_base(epi) == EPI_BIAS_RESID && a.K > a.N ? 100 : 0)) {
     VDR_LAUNCH(EPI_BIAS)
     VDR_LAUNCH(EPI_BIAS_GELU)
     VDR_LAUNCH(EPI_BIAS_RESID)
     VDR_LAUNCH_T(EPI_BIAS_RESID, 1)
+    VDR_LAUNCH(EPI_BIAS_RESID32)
+    VDR_LAUNCH_T(EPI_BIAS_RESID32, 1)
     VDR_LAUNCH(EPI_SWIGLU)
     VDR_LAUNCH(EPI_PATCH)
     default:

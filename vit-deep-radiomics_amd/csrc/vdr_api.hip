@@ -444,10 +444,14 @@ struct Carve {
   float* rel = nullptr;  // SAM: rel-pos products T[tokens][heads][relpos_npad(S)] (q . every table row)
   char *hs = nullptr, *us = nullptr, *os = nullptr;  // fp8 path: e8m0 scales of the MX activations kept in h, u, o
   char *cls_h = nullptr, *cls_u = nullptr, *cls_x = nullptr;  // fp8_cls_bf16: norm2 / activation / new residual rows of the CLS rows
+  float *x32 = nullptr, *xc32 = nullptr;  // resid_fp32: fp32 master copy of the residual stream [Mp, D] / of the compact CLS rows
   float *part, *stats;  // LayerNorm partial sums [D/64][Mp][2] and (mean, rstd) [Mp][2]
   int64_t Mp;
   size_t total;
 };
+
+// vdr_config.resid_fp32 applies to the bf16 path of pre-LN image models (plain ViTs: no SAM windows, no fp8)
+bool resid_fp32_on(const vdr_config& c) { return c.resid_fp32 && c.pre_ln && c.patch && !c.fp8 && c.window == 0; }
 
 Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
   const vdr_config& c = m->cfg;
@@ -497,6 +501,10 @@ Carve carve(const vdr_model* m, char* base, int mb, int ntok) {
       w.cls_u = take(rb * F * 2);
       w.cls_x = take(rb * D * 2);
     }
+  }
+  if (resid_fp32_on(c)) {
+    w.x32 = (float*)take(Mp * D * 4);
+    w.xc32 = (float*)take((size_t)round_up(mb, 256) * D * 4);
   }
   w.part = (float*)take((size_t)(D / 64 + 1) * Mp * 8);
   w.stats = (float*)take(Mp * 8);
@@ -657,7 +665,8 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
 
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold(),
-         int64_t lda = 0, int64_t ldr = 0) {  // lda / ldr: row strides of A / resid when they are not K / ldc
+         int64_t lda = 0, int64_t ldr = 0,  // lda / ldr: row strides of A / resid when they are not K / ldc
+         const float* resid32 = nullptr, float* C32 = nullptr) {  // resid_fp32: the fp32 residual stream in / out (same strides)
   GemmArgs g{};
   g.ln_stats = ln.stats;
   g.colsum = ln.colsum;
@@ -682,8 +691,11 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   g.ldc = ldc;
   g.ldr = ldr ? ldr : ldc;
   g.omap = identity_map();
+  g.resid32 = resid32;
+  g.C32 = C32;
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
-  Scope sc(m, s, cls, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid ? 2 : 1)));
+  Scope sc(m, s, cls, 2.0 * M * N * K,
+           2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid32 ? 5 : resid ? 2 : 1)));  // (fp32 in + fp32 out + bf16 out)
   VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, M, N), s), "gemm");
   return VDR_OK;
 }
@@ -812,11 +824,13 @@ int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L,
       return rc;
     return gemm_mx(m, s, VDR_K_GEMM_FC2, w.u, w.us, L.w2_q, L.w2_s, L.b2, xc, L.ls2, xc, nullptr, mb, D, F, D, EPI_BIAS_RESID);
   }
+  const float* r32 = w.x32;  // resid_fp32: the CLS rows' fp32 residual comes from x32 (strided) and stays in xc32 (compact)
+  float* c32 = w.x32 ? w.xc32 : nullptr;
   if (m->ln_fuse) {
     LnFold prod, cons;
     prod.part = w.part;
     prod.part_stride = w.Mp;
-    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, prod, stride, stride)))
+    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, prod, stride, stride, r32, c32)))
       return rc;
     if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, mb, sw ? 2 * F : F, D, w, &cons))) return rc;
     cons.colsum = L.s1;
@@ -825,14 +839,15 @@ int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L,
       return rc;
   } else {
     char* hc = w.h + (size_t)round_up(mb, 256) * D * 2;  // norm2 of the compact rows (w.h holds Mp >= mb * ntok + 256 rows)
-    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, LnFold(), stride, stride)))
+    if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, LnFold(), stride, stride, r32, c32)))
       return rc;
-    if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xc, 1, hc, 1, L.n2w, L.n2b, mb, identity_map()))) return rc;
+    if ((rc = layernorm(m, s, VDR_K_LAYERNORM, c32 ? (const void*)c32 : (const void*)xc, c32 ? 0 : 1, hc, 1, L.n2w, L.n2b, mb, identity_map())))
+      return rc;
     if ((rc = gemm(m, s, VDR_K_GEMM_FC1, hc, L.w1, L.b1, nullptr, nullptr, w.u, mb, sw ? 2 * F : F, D, F,
                    sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
       return rc;
   }
-  return gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, xc, L.ls2, xc, mb, D, F, D, EPI_BIAS_RESID);
+  return gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, xc, L.ls2, xc, mb, D, F, D, EPI_BIAS_RESID, LnFold(), 0, 0, c32, c32);
 }
 
 // cls_tail: the caller only wants the CLS rows (see block_tail_cls); *compact is set when they were left in w.h [mb, D]
@@ -921,21 +936,26 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         *compact = true;
         return block_tail_cls(m, s, w, L, mb, ntok);
       }
-      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, prod, 0, 0, w.x32, w.x32)))
+        return rc;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
                      sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
         return rc;
-      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod, 0, 0, w.x32, w.x32)))
+        return rc;
     }
     return VDR_OK;
   }
   for (int i = 0; i < c.layers; ++i) {
     const LayerW& L = m->layers[i];
     const void* attn_in = w.x;
+    // (resid_fp32: the explicit LayerNorm reads the fp32 master copy of the stream)
+    const void* xin = w.x32 ? (const void*)w.x32 : (const void*)w.x;
+    const int xin_bf16 = w.x32 ? 0 : 1;
     if (c.pre_ln) {
-      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xin, xin_bf16, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
       attn_in = w.h;
     }
     if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS)))
@@ -950,12 +970,14 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       return block_tail_cls(m, s, w, L, mb, ntok);
     }
     if (c.pre_ln) {
-      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID))) return rc;
-      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.x, M, D, D, D, EPI_BIAS_RESID, LnFold(), 0, 0, w.x32, w.x32)))
+        return rc;
+      if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xin, xin_bf16, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.h, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
                      sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
         return rc;
-      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, LnFold(), 0, 0, w.x32, w.x32)))
+        return rc;
     } else {
       // nn.TransformerEncoderLayer, norm_first=False: x = LN1(x + SA(x)); x = LN2(x + FF(x))
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.h, M, D, D, D, EPI_BIAS_RESID))) return rc;
@@ -1127,6 +1149,7 @@ int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_
   const int ncls = c.has_cls ? 1 : 0;
   if (compact) {
     const int ob = out_dtype == VDR_BF16;
+    if (w.x32) return layernorm(m, s, VDR_K_FINAL_LN, w.xc32, 0, out, ob, m->normw, m->normb, mb, identity_map());
     return layernorm(m, s, VDR_K_FINAL_LN, w.h, 1, out, ob, m->normw, m->normb, mb, identity_map());
   }
   if (out_mode == VDR_OUT_CLS) {
@@ -1140,7 +1163,10 @@ int emit(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, int out_
     rows = (int64_t)mb * ntok;
   }
   const int ob = out_dtype == VDR_BF16;
-  if (c.pre_ln) return layernorm(m, s, VDR_K_FINAL_LN, w.x, 1, out, ob, m->normw, m->normb, rows, im);
+  if (c.pre_ln) {
+    if (w.x32) return layernorm(m, s, VDR_K_FINAL_LN, w.x32, 0, out, ob, m->normw, m->normb, rows, im);
+    return layernorm(m, s, VDR_K_FINAL_LN, w.x, 1, out, ob, m->normw, m->normb, rows, im);
+  }
   Scope sc(m, s, VDR_K_FINAL_LN, 0.0, (double)rows * D * (2 + (ob ? 2 : 4)));
   VDR_TRY(launch_gather_rows(w.x, out, ob, rows, D, im, s), "gather_rows");
   return VDR_OK;
@@ -1205,6 +1231,7 @@ int vdr_create(const vdr_config* cfg, int device, vdr_handle* out) {
   if (c.act != VDR_ACT_GELU && c.act != VDR_ACT_SWIGLU) return fail(nullptr, VDR_ERR_INVALID, "unknown activation");
   if (c.fp8 && !c.pre_ln) return fail(nullptr, VDR_ERR_UNSUPPORTED, "fp8 weights: pre-LN models only");
   if (c.fp8_cls_bf16 < 0 || c.fp8_cls_bf16 > 1) return fail(nullptr, VDR_ERR_INVALID, "fp8_cls_bf16 must be 0 or 1");
+  if (c.resid_fp32 < 0 || c.resid_fp32 > 1) return fail(nullptr, VDR_ERR_INVALID, "resid_fp32 must be 0 or 1");
   if (c.fp8 < 0 || c.fp8 > 1)
     return fail(nullptr, VDR_ERR_UNSUPPORTED,
                 "fp8 must be 0 or 1 (a level that also quantised the out-projection measured 0.987 row cosine at 40 "
@@ -1481,6 +1508,10 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     if (c.input_ln) {
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.x, 1, m->inw, m->inb, (int64_t)mb * ntok, identity_map())))
         return rc;
+    }
+    if (w.x32) {  // resid_fp32: the stream's fp32 master copy starts from the assembled tokens (their one bf16 rounding stays)
+      Scope sc(m, s, VDR_K_ASSEMBLE, 0.0, (double)mb * ntok * D * 6);
+      VDR_TRY(launch_gather_rows(w.x, w.x32, 0, (int64_t)mb * ntok, D, identity_map(), s), "residual stream -> fp32");
     }
     bool compact = false;
     if ((rc = run_blocks(m, s, w, mb, ntok, nullptr, 0, out_mode == VDR_OUT_CLS, &compact))) return rc;

@@ -45,7 +45,9 @@ static inline RowMap identity_map() { return RowMap{1 << 30, 0, 0}; }
 
 enum Epilogue { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_SWIGLU = 3, EPI_PATCH = 4,
                 // internal to gemm_mx.hip: GELU / SwiGLU with the output re-quantised to MX-fp8
-                EPI_BIAS_GELU_MX = 5, EPI_SWIGLU_MX = 6 };
+                EPI_BIAS_GELU_MX = 5, EPI_SWIGLU_MX = 6,
+                // internal to launch_cfg: EPI_BIAS_RESID with the residual stream kept in fp32 (GemmArgs::resid32 / C32)
+                EPI_BIAS_RESID32 = 7 };
 
 struct GemmArgs {
   const void* A;      // [M, K] bf16, row stride lda
@@ -53,6 +55,10 @@ struct GemmArgs {
   int w_interleaved = 0;  // W is [N/2][K/32][2][32] (launch_w_interleave): whole-line operand loads, gemm_kernels.h
   const float* bias;  // [N] or null
   const void* resid;  // [*, ldr] bf16 (EPI_BIAS_RESID), indexed by the OUTPUT row
+  // vdr_config.resid_fp32 (ring3 / ring4 kernels, EPI_BIAS_RESID): the residual is READ from resid32 [*, ldr] fp32 instead of
+  // `resid`, the fp32 sum is written to C32 [*, ldc] fp32 AND, rounded once, to C (the bf16 copy the next GEMM multiplies)
+  const float* resid32 = nullptr;
+  float* C32 = nullptr;
   const float* gamma; // [N] LayerScale or null
   const float* pos;   // [tokens, N] fp32 (EPI_PATCH), indexed by off + r % rpg
   void* C;            // bf16, row stride ldc

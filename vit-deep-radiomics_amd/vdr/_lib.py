@@ -28,7 +28,7 @@ class vdr_config(C.Structure):
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
                 ("streams", C.c_int32), ("window", C.c_int32),
                 ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32),
-                ("full_last_block", C.c_int32), ("fp8_cls_bf16", C.c_int32)]
+                ("full_last_block", C.c_int32), ("fp8_cls_bf16", C.c_int32), ("resid_fp32", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)

@@ -38,6 +38,7 @@ class VdrConfig:
     full_last_block: bool = False  # CLS output: True keeps every row of the last block (default: its CLS rows only,
                                # the same features bit for bit; see vdr_config.full_last_block)
     fp8_cls_bf16: bool = False  # fp8 = 1: the MLP of the CLS rows on the bf16 weights (vdr_config.fp8_cls_bf16)
+    resid_fp32: bool = False  # bf16 path: fp32 master copy of the residual stream (vdr_config.resid_fp32)
 
     @property
     def n_patches(self):
@@ -61,6 +62,7 @@ class VdrConfig:
         c.no_ln_fold = int(not self.ln_fold)
         c.full_last_block = int(self.full_last_block)
         c.fp8_cls_bf16 = int(self.fp8_cls_bf16)
+        c.resid_fp32 = int(self.resid_fp32)
         return c
 
 
