@@ -117,7 +117,7 @@ def test_linear_rejects_unknown_and_ablation_variants(ops):
     import vdr
     x = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
     tuning = bool(vdr.load().vdr_tuning_build())  # a tools/ build accepts the ablation encodings
-    for bad in (5, 21, 31) + (() if tuning else (122, 822)):
+    for bad in (5, 21, 31, 32) + (() if tuning else (122, 822)):  # (31 exists, but not for a 64 x 64 problem)
         with pytest.raises(vdr.VdrError):
             ops.linear(x, x, None, variant=bad)
 
@@ -136,6 +136,47 @@ def test_linear_full_size_packed_equals_plain_bitwise(ops):
         Wp = ops.pack_linear_weight(W)
         for v in (22, 26, 27):
             assert torch.equal(a, ops.linear(x, Wp, b, epilogue=epi, variant=v, packed=True)), (N, K, v)
+
+
+def test_linear_8phase_variant_exact_and_bitwise(ops):
+    """Tile variant 31 (csrc/gemm_8p.hip: 256 x 256 x 64 tiles, one persistent 8-wave workgroup per CU, two M halves of the
+    waves ping-ponging load and MFMA segments, output stored from the accumulator layout in whole lines): (i) integer data
+    -> bit-exact against the fp32 reference, EPI_BIAS and the exact structure of every tile position (several tiles per
+    workgroup, a partial last round, K of 4 and of many K-tiles); (ii) random data at the headline shapes -> the bits of
+    ring3 / ring4 (same products, same summation order, same epilogue formula), erf-GELU included; (iii) launches it
+    does not take (too few tiles, ragged M / N, a residual epilogue) are refused, not mis-run."""
+    from vdr import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID
+    g = torch.Generator().manual_seed(31)
+    for (M, N, K) in [(256 * 64, 2048, 256), (256 * 130, 1024, 384), (256 * 512, 256, 256), (256 * 67, 2304, 1024)]:
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        W = torch.randint(-2, 3, (N, K), generator=g).float()
+        b = torch.randint(-3, 4, (N,), generator=g).float()
+        y = ops.linear(_bf(x).cuda(), _bf(W).cuda(), b.cuda(), epilogue=EPI_BIAS, variant=31)
+        ref = x.cuda() @ W.cuda().t() + b.cuda()
+        assert torch.equal(y.float(), _bf(ref.cpu()).cuda().float()), (M, N, K)
+        y0 = ops.linear(_bf(x).cuda(), _bf(W).cuda(), None, epilogue=EPI_BIAS, variant=31)  # no bias: the launcher's zeros
+        assert torch.equal(y0.float(), _bf((x.cuda() @ W.cuda().t()).cpu()).cuda().float()), (M, N, K, "no bias")
+    M = 50432
+    for (N, K, epi) in [(2304, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (768, 3072, EPI_BIAS), (3072, 768, EPI_BIAS)]:
+        x = _bf(torch.randn(M, K, generator=g)).cuda()
+        W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        a = ops.linear(x, W, b, epilogue=epi, variant=22)
+        y = torch.full_like(a, 7.0)
+        for _ in range(3):  # three launches in a row: the kernel leaves no state behind
+            ops.linear(x, W, b, epilogue=epi, variant=31, out=y)
+            assert torch.equal(a, y), (N, K, epi)
+        assert torch.equal(a, ops.linear(x, ops.pack_linear_weight(W), b, epilogue=epi, variant=26, packed=True)), (N, K, epi)
+    xs = _bf(torch.randn(4096, 768, generator=g)).cuda()
+    Ws = _bf(torch.randn(768, 768, generator=g)).cuda()
+    for bad in (dict(x=xs, W=Ws),                                           # 48 tiles: not worth a persistent launch
+                dict(x=_bf(torch.randn(50432 + 8, 768, generator=g)).cuda(), W=_bf(torch.randn(2304, 768, generator=g)).cuda()),   # M % 256
+                dict(x=_bf(torch.randn(50432, 768, generator=g)).cuda(), W=_bf(torch.randn(2304 + 64, 768, generator=g)).cuda())):  # N % 256
+        with pytest.raises(RuntimeError):
+            ops.linear(bad["x"], bad["W"], None, variant=31)
+    with pytest.raises(RuntimeError):
+        big = _bf(torch.randn(50432, 768, generator=g)).cuda()
+        ops.linear(big, _bf(torch.randn(768, 768, generator=g)).cuda(), None, resid=big, epilogue=EPI_BIAS_RESID, variant=31)
 
 
 def test_linear_many_tiles_exact(ops):

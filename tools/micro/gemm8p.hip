@@ -194,9 +194,18 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(G8 p) {
         db[d] = lower ? recv : w1[d];  // rows 8-15:             row r+8's block 0 | own block 1
       }
       if (!(p.dbg & 1) && (!(p.dbg & 8) || ((blockIdx.x >> 3) & 7) == 0)) {
-        if (p.dbg & 16) {  // diagnostic: non-temporal stores
-          __builtin_nontemporal_store(da, reinterpret_cast<u32x4*>(crow + (size_t)(16 * i) * p.N));
-          __builtin_nontemporal_store(db, reinterpret_cast<u32x4*>(crow + (size_t)(16 * i + 8) * p.N));
+        // diagnostic: cache policy of the output stores (dbg & 0x70): 16 nt, 32 sc1, 48 sc0 sc1, 64 sc0 sc1 nt
+        const int pol = (p.dbg >> 4) & 7;
+        if (pol) {
+          // (the descriptor from the wave-uniform base, the lane part in the offset: a per-lane base makes hipcc wrap every
+          // store in a waterfall loop -- cdna_hip_programming.md T20 -- which is what a first version of this measured: 5x)
+          auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, (short)0, 0x7fffffff, 0x00020000);
+          const int lane_off = (int)((const char*)crow - (const char*)p.C);
+          const int o0 = lane_off + (16 * i) * p.N * 2, o1 = lane_off + (16 * i + 8) * p.N * 2;
+          if (pol == 1) { __builtin_amdgcn_raw_buffer_store_b128(da, rs, o0, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(db, rs, o1, 0, 2); }
+          else if (pol == 2) { __builtin_amdgcn_raw_buffer_store_b128(da, rs, o0, 0, 16); __builtin_amdgcn_raw_buffer_store_b128(db, rs, o1, 0, 16); }
+          else if (pol == 3) { __builtin_amdgcn_raw_buffer_store_b128(da, rs, o0, 0, 17); __builtin_amdgcn_raw_buffer_store_b128(db, rs, o1, 0, 17); }
+          else { __builtin_amdgcn_raw_buffer_store_b128(da, rs, o0, 0, 19); __builtin_amdgcn_raw_buffer_store_b128(db, rs, o1, 0, 19); }
         } else {
           *reinterpret_cast<u32x4*>(crow + (size_t)(16 * i) * p.N) = da;
           *reinterpret_cast<u32x4*>(crow + (size_t)(16 * i + 8) * p.N) = db;
@@ -480,7 +489,7 @@ int main(int argc, char** argv) {
     const double gf = 2.0 * Ms * N * (double)K;
     printf("%s M %d: 8-phase %7.1f us (min %7.1f) %6.0f TF/s | ring4 %7.1f us (min %7.1f) %6.0f TF/s | ratio %.3f | bitwise-vs-ring4 diffs %zu | max rel err vs f64 %.2e | grid %d\n",
            s.name, Ms, med(t8), mn(t8), gf / med(t8) / 1e6, med(t4), mn(t4), ring4 ? gf / med(t4) / 1e6 : 0.0, ring4 ? med(t8) / med(t4) : 0.0, diff, maxerr, grid);
-    for (int dbg : {1, 8, 16, 8 << 8}) {
+    for (int dbg : {1, 16, 32, 48, 64}) {
       g.dbg = dbg;
       std::vector<float> td;
       for (int rd = 0; rd < 5; ++rd) {
@@ -492,7 +501,7 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         td.push_back(ms * 1e3f / NB);
       }
-      printf("      dbg %5d (%s): %7.1f us\n", dbg, dbg == 1 ? "no stores" : dbg == 8 ? "1 workgroup in 8 stores" : dbg == 16 ? "non-temporal stores" : "start staggered over dbg>>8 us", med(td));
+      printf("      dbg %5d (%s): %7.1f us\n", dbg, dbg == 1 ? "no stores" : dbg == 8 ? "1 workgroup in 8 stores" : dbg == 16 ? "stores nt" : dbg == 32 ? "stores sc1" : dbg == 48 ? "stores sc0 sc1" : dbg == 64 ? "stores sc0 sc1 nt" : "start staggered over dbg>>8 us", med(td));
     }
     g.dbg = 0;
     fflush(stdout);

@@ -10,6 +10,7 @@
 namespace vdr {
 
 hipError_t launch_gemm_ring4(const GemmArgs& a, int epilogue, int variant, hipStream_t s);  // gemm_ring4.hip
+hipError_t launch_gemm_8p(const GemmArgs& a, int epilogue, hipStream_t s);                   // gemm_8p.hip
 
 // [N][K] (row stride ld) -> pair-interleaved [N/2][K/32][2][32]; one 16-byte chunk per thread
 __global__ __launch_bounds__(256) void w_interleave_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K,
@@ -57,6 +58,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t
     case 28:
     case 29:
       return launch_gemm_ring4(a, epilogue, variant, s);
+    case 31:
+      return launch_gemm_8p(a, epilogue, s);  // 8-phase: 256x256 tile, 8 waves, one persistent workgroup per CU, plain W layout
     default:
       return hipErrorInvalidValue;  // (variants 0-21, the earlier rungs of the ladder in DESIGN.md, are no longer built; 30, the persistent stream kernel of round 3, lives in tools/micro/)
   }

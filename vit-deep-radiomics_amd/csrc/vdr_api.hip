@@ -618,6 +618,10 @@ bool patch_gather_ok(int in_dtype, int patch, int variant, const void* images) {
          ((uintptr_t)images & 15) == 0;
 }
 
+#ifndef VDR_GEMM_8P_DEFAULT
+#define VDR_GEMM_8P_DEFAULT 1  // qkv (measured in the forward: qkv 172 -> 147 us per launch; fc1 with its erf-GELU 254 vs ring4 249: stays on ring4)
+#endif
+
 struct LnFold {
   const float* stats = nullptr;   // consumer: (mean, rstd) per row
   const float* colsum = nullptr;  // consumer: column sums of the folded weight
@@ -628,6 +632,15 @@ struct LnFold {
   int64_t cstride = 0;
   float inv_d = 0.0f, eps = 0.0f;
 };
+
+// which GEMM classes take tile variant 31 when the launch is eligible (gemm_8p_eligible): measured per class in the
+// forward; tuning builds: VDR_GEMM_8P = bit mask (1 qkv, 2 fc1), -1 = the default
+bool use_8p(const vdr_model* m, int cls) {
+  (void)m;
+  VDR_KNOB int mask_env = env_int("VDR_GEMM_8P", -1);
+  const int mask = mask_env >= 0 ? mask_env : VDR_GEMM_8P_DEFAULT;
+  return (cls == VDR_K_GEMM_QKV && (mask & 1)) || (cls == VDR_K_GEMM_FC1 && (mask & 2));
+}
 
 // Where the (sum, sumsq) partials of the residual stream become (mean, rstd): inside the consuming GEMM when it runs
 // a ring3 variant (22-24; every workgroup finalises its own rows in LDS while its ring fills: no launch), otherwise by
@@ -641,6 +654,8 @@ bool ln_stats_in_gemm(int cls, int64_t M, int N, int groups) {
   const int v = gemm_variant_for(cls, M, N);
   if (mode == 0 || groups > 16 || v < 22 || v == 25 || v > 28) return false;
   if (mode == 1) return true;
+  // (a launch the 8-phase kernel takes reads finalised statistics: it has no in-GEMM finalisation)
+  if (use_8p(nullptr, cls) && (N & 255) == 0 && (M >> 8) * (int64_t)(N >> 8) >= 512) return false;
   return ((M + 127) / 128) * ((N + 255) / 256) <= 2048;
 }
 
@@ -696,7 +711,23 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K,
            2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid32 ? 5 : resid ? 2 : 1)));  // (fp32 in + fp32 out + bf16 out)
-  VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, M, N), s), "gemm");
+  // Tile variant 31 (gemm_8p.hip) for the write-once linears of large launches: the rows up to the last multiple of 256
+  // go to the 8-phase kernel (plain weight layout), what is left (< 256 rows) to the ring4 tiles -- rows are independent
+  // and both kernels sum K in the same order with the same epilogue arithmetic: the output is the same bits either way.
+  if (use_8p(m, cls) && lda == 0) {
+    GemmArgs h = g;
+    h.M = M & ~(int64_t)255;
+    if (h.M > 0 && gemm_8p_eligible(h, epi)) {
+      VDR_TRY(launch_gemm(h, epi, 31, s), "gemm_8p");
+      const int64_t done = h.M;
+      if (done == M) return VDR_OK;
+      g.A = (const char*)g.A + (size_t)done * g.lda * 2;
+      g.C = (char*)g.C + (size_t)done * g.ldc * 2;
+      if (g.ln_stats) g.ln_stats += 2 * done;
+      g.M = M - done;
+    }
+  }
+  VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, g.M, N), s), "gemm");
   return VDR_OK;
 }
 

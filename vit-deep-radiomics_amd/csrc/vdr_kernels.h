@@ -97,6 +97,9 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
+// whether tile variant 31 (gemm_8p.hip: the 256 x 256 x 64 8-phase kernel, one workgroup per CU) takes this launch: EPI_BIAS /
+// EPI_BIAS_GELU with a plain bf16 output, plain weight layout, M % 256 == 0, N % 256 == 0, K % 128 == 0, >= 512 tiles
+bool gemm_8p_eligible(const GemmArgs& a, int epilogue);
 // [N][K] bf16 (row stride ld elements) -> the pair-interleaved weight layout (N even, K % 32 == 0)
 hipError_t launch_w_interleave(const void* src, void* dst, int N, int K, int64_t ld, hipStream_t s);
 
