@@ -372,16 +372,16 @@ def main():
         dv = prof_dom[dom]
         ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r03_pmc_traffic.*): PMC counters cannot be
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/r04_pmc_traffic.*): PMC counters cannot be
         # collected from inside this process, so the number is the profiled one for the same launch shape -- and only
         # while the kernels are the profiled ones: the file carries vdr.source_id() (sha256 over csrc/) of its run
-        traffic, traffic_note = None, "profiles/r03_pmc_traffic.txt"
+        traffic, traffic_note = None, "profiles/r04_pmc_traffic.txt"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS)", "attention": "attention",
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS, 8-phase)", "attention": "attention",
                    "gemm_fc2": "gemm_fc2 (EPI_BIAS_RESID, K > N)", "gemm_proj": "gemm_proj (EPI_BIAS_RESID, K = N)"}.get(dom)
             if pm.get("_source_id") != vdr.source_id():
-                traffic_note = f"dropped: profiles/r03_pmc_traffic.json was taken with kernel sources {pm.get('_source_id')}, this run has {vdr.source_id()}"
+                traffic_note = f"dropped: profiles/r04_pmc_traffic.json was taken with kernel sources {pm.get('_source_id')}, this run has {vdr.source_id()}"
             elif key in pm and a.model == "vit_base16_224" and B == 256:
                 traffic = round((pm[key]["read_mb_corrected"] + pm[key]["write_mb"]) * 1e6)
         except Exception as e:

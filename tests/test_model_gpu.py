@@ -683,6 +683,16 @@ def test_full_batch_properties_at_baseline_size():
     assert torch.equal(out_p, out[perm])
     small = e.forward(x[100:103], vdr.OUT_CLS)
     assert torch.equal(small, out[100:103])
+    # The qkv linears of these launches run on tile variant 31 (csrc/gemm_8p.hip: 256-row tiles, one workgroup per CU), those
+    # of the 3-image run on the ring4 tiles: the comparison above is 8-phase == ring4 bit for bit, LayerNorm fold included.
+    # A batch whose token count is NOT a multiple of 256 (100 images = 19700 rows: 693 tiles, the last row tile 244 rows):
+    # the kernel reads the workspace's padding rows behind row M and stores none of them -- every token, fold on and off.
+    for fold in (True, False):
+        ef = _engine(cfg, w, ln_fold=fold)
+        big = ef.forward(x[:100].contiguous(), vdr.OUT_TOKENS)
+        assert torch.isfinite(big.float()).all()
+        for lo in (0, 47, 97):
+            assert torch.equal(ef.forward(x[lo:lo + 3].contiguous(), vdr.OUT_TOKENS), big[lo:lo + 3]), (fold, lo)
 
 
 # ---- SAM / MedSAM image encoder (the reference's default backbone) ----------------

@@ -147,7 +147,7 @@ def test_linear_8phase_variant_exact_and_bitwise(ops):
     does not take (too few tiles, ragged M / N, a residual epilogue) are refused, not mis-run."""
     from vdr import EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID
     g = torch.Generator().manual_seed(31)
-    for (M, N, K) in [(256 * 64, 2048, 256), (256 * 130, 1024, 384), (256 * 512, 256, 256), (256 * 67, 2304, 1024)]:
+    for (M, N, K) in [(256 * 64, 2048, 256), (256 * 128, 1024, 384), (256 * 512, 256, 256), (256 * 85, 2304, 1024)]:
         x = torch.randint(-2, 3, (M, K), generator=g).float()
         W = torch.randint(-2, 3, (N, K), generator=g).float()
         b = torch.randint(-3, 4, (N,), generator=g).float()
@@ -157,7 +157,7 @@ def test_linear_8phase_variant_exact_and_bitwise(ops):
         y0 = ops.linear(_bf(x).cuda(), _bf(W).cuda(), None, epilogue=EPI_BIAS, variant=31)  # no bias: the launcher's zeros
         assert torch.equal(y0.float(), _bf((x.cuda() @ W.cuda().t()).cpu()).cuda().float()), (M, N, K, "no bias")
     M = 50432
-    for (N, K, epi) in [(2304, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (768, 3072, EPI_BIAS), (3072, 768, EPI_BIAS)]:
+    for (N, K, epi) in [(2304, 768, EPI_BIAS), (3072, 768, EPI_BIAS_GELU), (1536, 1536, EPI_BIAS), (3072, 768, EPI_BIAS)]:
         x = _bf(torch.randn(M, K, generator=g)).cuda()
         W = _bf(torch.randn(N, K, generator=g) * 0.05).cuda()
         b = torch.randn(N, generator=g).cuda()
@@ -170,6 +170,7 @@ def test_linear_8phase_variant_exact_and_bitwise(ops):
     xs = _bf(torch.randn(4096, 768, generator=g)).cuda()
     Ws = _bf(torch.randn(768, 768, generator=g)).cuda()
     for bad in (dict(x=xs, W=Ws),                                           # 48 tiles: not worth a persistent launch
+                dict(x=_bf(torch.randn(256 * 67, 768, generator=g)).cuda(), W=_bf(torch.randn(2304, 768, generator=g)).cuda()),  # 603 tiles = 2.4 rounds: the last one 35 % full
                 dict(x=_bf(torch.randn(50432 + 8, 768, generator=g)).cuda(), W=_bf(torch.randn(2304, 768, generator=g)).cuda()),   # M % 256
                 dict(x=_bf(torch.randn(50432, 768, generator=g)).cuda(), W=_bf(torch.randn(2304 + 64, 768, generator=g)).cuda())):  # N % 256
         with pytest.raises(RuntimeError):

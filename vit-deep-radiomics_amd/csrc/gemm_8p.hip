@@ -31,8 +31,10 @@
 //     LDS-DMA too, double buffered by tile parity: no vector-memory load in the kernel is a plain load, so every counted
 //     vmcnt written here is exact (LDS-DMA pieces and stores count together, in issue order).
 // Same products in the same order and the same epilogue formula as ring3 / ring4: outputs are bitwise equal
-// (tests/test_ops_gpu.py::test_linear_8phase_*).  Shapes: M % 256 == 0 (the caller gives the remaining rows to ring4),
-// N % 256 == 0, K % 128 == 0, K >= 256, at least 512 tiles.
+// (tests/test_ops_gpu.py::test_linear_8phase_*).  Shapes: N % 256 == 0, K % 128 == 0, K >= 256; M % 256 == 0, or A / the row
+// statistics readable up to M rounded up to 256 (GemmArgs::a_rows: the forward's workspace buffers are) -- the rows of the
+// last tile past M are computed from whatever is there and never stored; enough tiles to fill the chip evenly
+// (gemm_8p_eligible: ViT-g/14 at batch 32 has 594 tiles = 2.3 rounds of 256 workgroups and stays on ring4).
 #include <utility>
 
 #include "gemm_kernels.h"
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
   // the accumulator layout:  v = fma(rs, acc, fma(-rs mu, csum, bias)), erf-GELU, one bf16 rounding.  A lane holds 16 B of
   // output row r in each 32-column block (p = 0, 1); lanes r and r ^ 8 exchange one block so that a store instruction
   // covers 8 rows x 128 B instead of 16 rows x 64 B.
-  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, (short)0, 0x7fffffff, 0x00020000);
+  // (the descriptor ends after the last valid row: the rows of a ragged last tile past M are dropped by the range check)
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, (short)0, p.M * p.ldc * 2, 0x00020000);
   auto epi_tiles = [&](auto mh_, auto i0_, int m0, int n0, int par) {
     constexpr int mh = decltype(mh_)::value, i0 = decltype(i0_)::value;
     const uint32_t cb = lds0 + LDS_CONST + par * 4096;
@@ -387,18 +390,32 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
 }  // namespace
 
 // whether tile variant 31 takes this launch (and is expected to pay: many tiles, a write-once bf16 output)
+// the tile-count rule alone: one workgroup per CU walks tiles / CUs rounds -- at least two, and the last one reasonably full
+// (a 2.3-round launch runs 3 rounds long: measured on ViT-g/14's qkv, 594 tiles: 114 us against ring4's 107)
+bool gemm_8p_shape_ok(int64_t M, int N) {
+  if (M <= 0 || (N & 255)) return false;
+  int n_cu = device_cu_count(current_device_index());
+  if (n_cu <= 0) n_cu = 256;
+  const int64_t tiles = ((M + 255) / 256) * (int64_t)(N / 256), slots = n_cu & ~7;
+  if (tiles < 2 * slots) return false;
+  const int64_t rounds = (tiles + slots - 1) / slots;
+  return (double)tiles >= 0.85 * (double)(rounds * slots);
+}
+
 bool gemm_8p_eligible(const GemmArgs& a, int epi) {
   if (epi != EPI_BIAS && epi != EPI_BIAS_GELU) return false;
   if (a.out_f32 || a.win_ws || a.a_rpg || a.patch_p || a.ln_part || a.ln_cpart || a.w_interleaved || a.resid32 || a.C32) return false;
   if (a.omap.rpg < (1 << 30) || a.a_scale || a.w_scale || a.c_scale) return false;
-  if (a.M <= 0 || (a.M & 255) || (a.N & 255) || (a.K & 127) || a.K < 256) return false;
+  if (a.M <= 0 || (a.N & 255) || (a.K & 127) || a.K < 256) return false;
+  const int64_t Mr = (a.M + 255) & ~(int64_t)255;
+  if (Mr != a.M && a.a_rows < Mr) return false;  // a ragged last tile reads 256 rows of A (and of the row statistics)
   if (a.lda < a.K || a.ldw < a.K || a.ldc < a.N) return false;
   if ((a.ln_stats != nullptr) != (a.colsum != nullptr)) return false;
-  if ((double)a.M * a.ldc * 2.0 >= 2147483648.0 || (double)a.M * a.lda * 2.0 >= 4294967296.0 || (double)a.N * a.ldw * 2.0 >= 4294967296.0)
+  if ((double)Mr * a.ldc * 2.0 >= 2147483648.0 || (double)Mr * a.lda * 2.0 >= 4294967296.0 || (double)a.N * a.ldw * 2.0 >= 4294967296.0)
     return false;  // 32-bit store offsets / lane offsets
   if (((uintptr_t)a.A | (uintptr_t)a.W | (uintptr_t)a.C) & 15) return false;
   if ((a.lda | a.ldw | a.ldc) & 7) return false;
-  return (a.M / 256) * (int64_t)(a.N / 256) >= 512;
+  return gemm_8p_shape_ok(a.M, a.N);
 }
 
 hipError_t launch_gemm_8p(const GemmArgs& a, int epi, hipStream_t s) {
@@ -421,7 +438,7 @@ hipError_t launch_gemm_8p(const GemmArgs& a, int epi, hipStream_t s) {
     bias = zeros[dev];
   }
   G8 g{(const bf16_t*)a.A, (const bf16_t*)a.W, bias, a.colsum, a.ln_stats, (bf16_t*)a.C, (int)a.M, a.N, a.K,
-       (int)a.lda, (int)a.ldw, (int)a.ldc, a.N / 256, (int)((a.M / 256) * (a.N / 256)), 0};
+       (int)a.lda, (int)a.ldw, (int)a.ldc, a.N / 256, (int)(((a.M + 255) / 256) * (a.N / 256)), 0};
   g.nt_store = (double)a.M * (double)a.ldc * 2.0 >= 128e6 ? 1 : 0;  // as launch_cfg: outputs larger than half the Infinity Cache
   int n_cu = device_cu_count(dev);
   if (n_cu <= 0) n_cu = 256;

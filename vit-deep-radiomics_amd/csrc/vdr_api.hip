@@ -655,7 +655,7 @@ bool ln_stats_in_gemm(int cls, int64_t M, int N, int groups) {
   if (mode == 0 || groups > 16 || v < 22 || v == 25 || v > 28) return false;
   if (mode == 1) return true;
   // (a launch the 8-phase kernel takes reads finalised statistics: it has no in-GEMM finalisation)
-  if (use_8p(nullptr, cls) && (N & 255) == 0 && (M >> 8) * (int64_t)(N >> 8) >= 512) return false;
+  if (use_8p(nullptr, cls) && gemm_8p_shape_ok(M, N)) return false;
   return ((M + 127) / 128) * ((N + 255) / 256) <= 2048;
 }
 
@@ -681,7 +681,8 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
 int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, const float* bias, const void* resid,
          const float* gamma, void* C, int64_t M, int N, int K, int ldc, int epi, const LnFold& ln = LnFold(),
          int64_t lda = 0, int64_t ldr = 0,  // lda / ldr: row strides of A / resid when they are not K / ldc
-         const float* resid32 = nullptr, float* C32 = nullptr) {  // resid_fp32: the fp32 residual stream in / out (same strides)
+         const float* resid32 = nullptr, float* C32 = nullptr,  // resid_fp32: the fp32 residual stream in / out (same strides)
+         int64_t a_rows = 0) {  // rows of A / of the fold's row statistics that are readable (workspace buffers: Mp); 0 = unknown
   GemmArgs g{};
   g.ln_stats = ln.stats;
   g.colsum = ln.colsum;
@@ -711,20 +712,13 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
   const double outw = epi == EPI_SWIGLU ? N / 2 : N;
   Scope sc(m, s, cls, 2.0 * M * N * K,
            2.0 * ((double)M * K + (double)N * K + (double)M * outw * (resid32 ? 5 : resid ? 2 : 1)));  // (fp32 in + fp32 out + bf16 out)
-  // Tile variant 31 (gemm_8p.hip) for the write-once linears of large launches: the rows up to the last multiple of 256
-  // go to the 8-phase kernel (plain weight layout), what is left (< 256 rows) to the ring4 tiles -- rows are independent
-  // and both kernels sum K in the same order with the same epilogue arithmetic: the output is the same bits either way.
-  if (use_8p(m, cls) && lda == 0) {
-    GemmArgs h = g;
-    h.M = M & ~(int64_t)255;
-    if (h.M > 0 && gemm_8p_eligible(h, epi)) {
-      VDR_TRY(launch_gemm(h, epi, 31, s), "gemm_8p");
-      const int64_t done = h.M;
-      if (done == M) return VDR_OK;
-      g.A = (const char*)g.A + (size_t)done * g.lda * 2;
-      g.C = (char*)g.C + (size_t)done * g.ldc * 2;
-      if (g.ln_stats) g.ln_stats += 2 * done;
-      g.M = M - done;
+  // Tile variant 31 (gemm_8p.hip) for the write-once linears of large launches (plain weight layout).  The workspace
+  // buffers A points into hold Mp >= M + 256 rows, so a ragged last 256-row tile reads rows that exist; they are never stored.
+  if (use_8p(m, cls) && lda == 0 && a_rows > 0) {
+    g.a_rows = a_rows;
+    if (gemm_8p_eligible(g, epi)) {
+      VDR_TRY(launch_gemm(g, epi, 31, s), "gemm_8p");
+      return VDR_OK;
     }
   }
   VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, g.M, N), s), "gemm");
@@ -956,7 +950,8 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       LnFold cons;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_QKV, M, 3 * D, D, w, &cons))) return rc;
       cons.colsum = L.sqkv;
-      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons)))
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, w.x, L.wqkv_f, L.tqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, cons, 0, 0, nullptr,
+                     nullptr, w.Mp)))
         return rc;
       {
         Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -989,7 +984,8 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xin, xin_bf16, w.h, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
       attn_in = w.h;
     }
-    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS)))
+    if ((rc = gemm(m, s, VDR_K_GEMM_QKV, attn_in, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, M, 3 * D, D, 3 * D, EPI_BIAS, LnFold(), 0, 0, nullptr,
+                   nullptr, w.Mp)))
       return rc;
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)ntok * ntok * 64.0 * H * mb, 2.0 * (double)M * 4 * D);
@@ -1095,7 +1091,9 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
         Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * D * 4);  // (own block: the profiler bracket must close before the GEMM)
         VDR_TRY(launch_layernorm(a, s), "layernorm(window)");
       }
-      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_QKV, hbuf, L.wqkv, L.bqkv, nullptr, nullptr, w.qkv, T, 3 * D, D, 3 * D, EPI_BIAS, LnFold(), 0, 0, nullptr,
+                     nullptr, w.Mp)))
+        return rc;
     }
     {
       Scope sc(m, s, VDR_K_ATTENTION, 4.0 * (double)S * S * S * S * 64.0 * H * nb + 2.0 * T * H * relpos_npad(S) * 64,

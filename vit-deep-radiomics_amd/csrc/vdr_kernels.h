@@ -59,6 +59,10 @@ struct GemmArgs {
   // `resid`, the fp32 sum is written to C32 [*, ldc] fp32 AND, rounded once, to C (the bf16 copy the next GEMM multiplies)
   const float* resid32 = nullptr;
   float* C32 = nullptr;
+  // rows of A (and of ln_stats) that are READABLE memory, >= M (0 = M).  Tile variant 31 loads whole 256-row tiles: it takes
+  // a ragged M only when the buffers are readable up to M rounded up to 256 (the forward's workspace is); rows past M are
+  // never stored (the store descriptor ends after row M - 1)
+  int64_t a_rows = 0;
   const float* gamma; // [N] LayerScale or null
   const float* pos;   // [tokens, N] fp32 (EPI_PATCH), indexed by off + r % rpg
   void* C;            // bf16, row stride ldc
@@ -98,8 +102,10 @@ struct GemmArgs {
 
 hipError_t launch_gemm(const GemmArgs& a, int epilogue, int variant, hipStream_t s);
 // whether tile variant 31 (gemm_8p.hip: the 256 x 256 x 64 8-phase kernel, one workgroup per CU) takes this launch: EPI_BIAS /
-// EPI_BIAS_GELU with a plain bf16 output, plain weight layout, M % 256 == 0, N % 256 == 0, K % 128 == 0, >= 512 tiles
+// EPI_BIAS_GELU with a plain bf16 output, plain weight layout, N % 256 == 0, K % 128 == 0, M % 256 == 0 or a_rows covering the
+// last 256-row tile, at least 2 tiles per CU with the last round of workgroups at least 85 % full
 bool gemm_8p_eligible(const GemmArgs& a, int epilogue);
+bool gemm_8p_shape_ok(int64_t M, int N);  // its tile-count rule alone
 // [N][K] bf16 (row stride ld elements) -> the pair-interleaved weight layout (N even, K % 32 == 0)
 hipError_t launch_w_interleave(const void* src, void* dst, int N, int K, int64_t ld, hipStream_t s);
 
