@@ -1,5 +1,8 @@
 // PARKED EXPERIMENT (round 3; was csrc/patch_fused.hip, vdr_op_patch_embed_fused / vdr_config.patch_fusion of ABI 6): bitwise
 // equal to im2col + GEMM and 1.6-2.1x slower (profiles/r03_patch_embed_fused_gbs.json) -- no longer compiled into libvdr.so.
+// Known issue if it is ever revived (round-3 advisor): the dynamic-LDS opt-in is remembered as a per-device bool although
+// lds = 32 (2 Kp + 32) varies at run time -- a first call with a smaller Kp leaves the attribute too low for a later one
+// (loud launch failure); keep the largest size set per device, as launch_cfg in gemm_kernels.h does.
 //
 // Patchify convolution in ONE launch for patch sides whose pixel runs are not 16-byte chunks (p = 14: DINOv2 /
 // ViT-L/14 / ViT-g/14) and for fp32 pixels of any even p (the reference's own input dtype):
