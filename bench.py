@@ -396,6 +396,14 @@ def main():
                 "flops_per_image_executed": flops_img, "flops_per_image_every_token": flops_ref,
                 "kernel_time_sum_ms_per_step": round(sum(v["ms"] for v in prof_all.values()), 3),
                 "kernels_table": f"average over {a.steps} steps (second, fully bracketed pass)"}
+        # north_star's own target is stated on the attention block (qkv projection + scaled-dot-product + out-projection):
+        # algorithmic FLOPs of those three classes over their summed launch time, against the same dense bf16 peak
+        blk = [prof_all[k] for k in ("gemm_qkv", "attention", "gemm_proj") if k in prof_all]
+        if len(blk) == 3 and not a.fp8:
+            bms = sum(v["ms"] for v in blk)
+            roof["attention_block"] = {"ms_per_step": round(bms, 3), "TFLOP/s": round(sum(v["flops"] for v in blk) / (bms * 1e-3) / 1e12, 1),
+                                       "frac": round(sum(v["flops"] for v in blk) / (bms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                       "target_frac": 0.60}
         out = {"metric": "images/sec, ViT-B/16 224^2 bf16 CLS-feature extraction" if a.model == "vit_base16_224"
                and not a.fp8 and not dense else ("slices/sec, MedSAM ViT-B 1024^2 dense descriptor (64,64,256)" + (" fp8 weights" if a.fp8 else "") if sam
                      else f"images/sec, {a.model}{' fp8 weights' if a.fp8 else ''} {'dense-descriptor' if dense else 'CLS-feature'} extraction"),
