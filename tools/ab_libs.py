@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Kernel-level A/B of two builds of libvdr.so in ONE process, interleaved rounds (guide rule 24): both libraries are
 dlopen'ed side by side and vdr_op_attention / vdr_op_linear_packed are called through ctypes on the same tensors.
-   python tools/ab_libs.py path/to/libA.so path/to/libB.so [attention|gemm]"""
+   python tools/ab_libs.py path/to/libA.so[:variant] path/to/libB.so[:variant] [attention|gemm]
+(":variant" = the tile variant handed to vdr_op_linear_packed by that side, e.g. the same library twice as lib.so:0 lib.so:31)"""
 import ctypes as C
 import sys
 
@@ -17,7 +18,9 @@ def load(path):
 
 
 def main():
-    libs = [load(sys.argv[1]), load(sys.argv[2])]
+    specs = [a.split(":") for a in sys.argv[1:3]]
+    libs = [load(sp[0]) for sp in specs]
+    variants = [int(sp[1]) if len(sp) > 1 else 0 for sp in specs]
     what = sys.argv[3] if len(sys.argv) > 3 else "attention"
     st = torch.cuda.current_stream().cuda_stream
     cases = []
@@ -38,8 +41,8 @@ def main():
             b = torch.randn(N, device="cuda")
             out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             for li, lib in enumerate(libs):
-                cases.append((f"gemm {name} lib{'AB'[li]}", lambda lib=lib, x=x, Wp=Wp, b=b, out=out, N=N, K=K, epi=epi:
-                              lib.vdr_op_linear_packed(x.data_ptr(), Wp.data_ptr(), b.data_ptr(), None, None, out.data_ptr(), M, N, K, epi, 0, st)))
+                cases.append((f"gemm {name} lib{'AB'[li]}", lambda lib=lib, x=x, Wp=Wp, b=b, out=out, N=N, K=K, epi=epi, v=variants[li]:
+                              lib.vdr_op_linear_packed(x.data_ptr(), Wp.data_ptr(), b.data_ptr(), None, None, out.data_ptr(), M, N, K, epi, v, st)))
     for _, f in cases:
         assert f() == 0
     torch.cuda.synchronize()

@@ -169,6 +169,12 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, (short)0, p.M * p.ldc * 2, 0x00020000);
   auto epi_tiles = [&](auto mh_, auto i0_, int m0, int n0, int par) {
     constexpr int mh = decltype(mh_)::value, i0 = decltype(i0_)::value;
+    // (the lane-derived addresses are rebuilt from an opaque copy of the lane id at every site: hoisted out of the K loop by
+    // hipcc they are long-lived registers of a kernel at its 256-register cap -- spilt, and a scratch reload inside the loop
+    // would count in vmcnt next to the LDS-DMA pieces)
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    const int r = lane_ & 15, q = lane_ >> 4;
     const uint32_t cb = lds0 + LDS_CONST + par * 4096;
     const uint32_t baddr = cb + (wc * 64 + 8 * q) * 4;
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
@@ -194,19 +200,22 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
           c1 = *reinterpret_cast<const lds_f32x4*>((uintptr_t)(baddr + 1024 + pb * 128 + 16));
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // epilogue_bf16's formula: two fused multiply-adds (without the fold rs = 1, nrm = 0, csum = 0: acc + bias exactly)
-          float v0 = fmaf(rs, acc[ii][2 * pb][e], fmaf(nrm, c0[e], b0[e]));
-          float v1 = fmaf(rs, acc[ii][2 * pb + 1][e], fmaf(nrm, c1[e], b1[e]));
+        for (int e = 0; e < 4; e += 2) {
+          // epilogue_bf16's formula: two fused multiply-adds (without the fold rs = 1, nrm = 0, csum = 0: acc + bias exactly),
+          // on pairs of neighbouring accumulator registers: v_pk_fma_f32, bit for bit the scalar operations, two per issue slot
+          const f32x2 rs2 = {rs, rs}, nrm2 = {nrm, nrm};
+          f32x2 v0 = __builtin_elementwise_fma(rs2, f32x2{acc[ii][2 * pb][e], acc[ii][2 * pb][e + 1]},
+                                               __builtin_elementwise_fma(nrm2, f32x2{c0[e], c0[e + 1]}, f32x2{b0[e], b0[e + 1]}));
+          f32x2 v1 = __builtin_elementwise_fma(rs2, f32x2{acc[ii][2 * pb + 1][e], acc[ii][2 * pb + 1][e + 1]},
+                                               __builtin_elementwise_fma(nrm2, f32x2{c1[e], c1[e + 1]}, f32x2{b1[e], b1[e + 1]}));
           if constexpr (EPI == EPI_BIAS_GELU) {
-            v0 = gelu_erf(v0);
-            v1 = gelu_erf(v1);
+            v0 = gelu_erf2(v0);
+            v1 = gelu_erf2(v1);
           }
-          ob[pb][e] = (bf16_t)v0;
-          ob[pb][4 + e] = (bf16_t)v1;
-          if constexpr (EPI == EPI_BIAS_GELU && FOLD) {
-            __builtin_amdgcn_sched_barrier(0);  // (two erf-GELU chains at a time, not sixteen: VGPR cap)
-          }
+          ob[pb][e] = (bf16_t)v0[0];
+          ob[pb][e + 1] = (bf16_t)v0[1];
+          ob[pb][4 + e] = (bf16_t)v1[0];
+          ob[pb][4 + e + 1] = (bf16_t)v1[1];
         }
         __builtin_amdgcn_sched_barrier(0);  // (keeps hipcc from fetching the next block's constants ahead: VGPR cap)
       });
@@ -290,6 +299,12 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
     const char* a2 = LAST ? na : ca;
     const char* w2 = LAST ? nw_ : cw;
     const int k2 = LAST ? 0 : t0 + 2, k3 = LAST ? 1 : t0 + 3;
+    // Where a finished M half leaves.  Waves 0-3 ("X") do it at the head of a load segment, waves 4-7 ("Y", one barrier
+    // behind) at the tail of the MFMA segment that faces it: the SAME slot of wall-clock time, so the two waves of a SIMD
+    // run their epilogues side by side (a wave issues one vector instruction per ~5.4 cycles, a SIMD takes one per ~2.7:
+    // profiles/r03_valu_rate_micro.txt) instead of one after the other with the partner's 16 MFMAs long finished --
+    // measured with every wave in its load segments: the erf-GELU cost 35 us of an fc1 launch, tools/ab_epi.py.
+    const bool X = wr == 0;
     // ---- K-tile t0, buffer 0 ----
     // phase 1: quadrant (m0, n0)
     read_b(I0{}, 0);
@@ -297,24 +312,39 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
     if constexpr (FIRST) stage_consts(m0, n0, par);
     stage(I1{}, ca, cw, t0 + 1, 1);  // A1 and W0 of t0 + 1 (buffer 1's W halves were last read in the previous pair's phase 8)
     stage(I2{}, ca, cw, t0 + 1, 1);
+    // (a tile's first pair stages W1 here too -- its half of buffer 1 was last read in the previous pair's phase 6 -- so that
+    // the stores of the previous tile's second M half, phases 1 to 3, are all BEHIND this K-tile's last piece: the counted
+    // wait of phase 4 never waits for the acknowledgement of a store)
+    if constexpr (FIRST) stage(I3{}, ca, cw, t0 + 1, 1);
     seg_sync_a();
     mfma_quadrant(I0{}, I0{}, std::integral_constant<bool, FIRST>{});
+    if constexpr (FIRST) {
+      if (have_prev && !X) {
+        __builtin_amdgcn_sched_barrier(0);
+        epi_tiles(I1{}, I0{}, pm0, pn0, par ^ 1);
+      }
+    }
     seg_sync_b();
     // phase 2: (m0, n1)
     read_b(I1{}, 0);
-    stage(I3{}, ca, cw, t0 + 1, 1);  // W1 of t0 + 1
-    // the previous tile's second M half (final after its phase 8) leaves in phases 2 and 3, BEHIND this K-tile's last
-    // piece: the counted wait of phase 4 never waits for the acknowledgement of a store
+    if constexpr (!FIRST) stage(I3{}, ca, cw, t0 + 1, 1);  // W1 of t0 + 1
+    // the previous tile's second M half (final after its phase 8) leaves in phases 2 and 3
     if constexpr (FIRST) {
-      if (have_prev) epi_tiles(I1{}, I0{}, pm0, pn0, par ^ 1);
+      if (have_prev && X) epi_tiles(I1{}, I0{}, pm0, pn0, par ^ 1);
     }
     seg_sync_a();
     mfma_quadrant(I0{}, I1{}, std::integral_constant<bool, FIRST>{});
+    if constexpr (FIRST) {
+      if (have_prev && !X) {
+        __builtin_amdgcn_sched_barrier(0);
+        epi_tiles(I1{}, I2{}, pm0, pn0, par ^ 1);
+      }
+    }
     seg_sync_b();
     // phase 3: (m1, n1)
     read_a(I1{}, 0);
     if constexpr (FIRST) {
-      if (have_prev) epi_tiles(I1{}, I2{}, pm0, pn0, par ^ 1);
+      if (have_prev && X) epi_tiles(I1{}, I2{}, pm0, pn0, par ^ 1);
     }
     seg_sync_a();
     mfma_quadrant(I1{}, I1{}, std::integral_constant<bool, FIRST>{});
@@ -342,20 +372,41 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
     stage(I3{}, a2, w2, k2, 0);  // W1 of t0 + 2
     seg_sync_a();
     mfma_quadrant(I0{}, I1{}, F{});
+    if constexpr (LAST) {
+      if (!X) {  // first M half (final with this segment), m-tiles 0, 1
+        __builtin_amdgcn_sched_barrier(0);
+        epi_tiles(I0{}, I0{}, m0, n0, par);
+      }
+    }
     seg_sync_b();
     // phase 7: (m1, n1)
     read_a(I1{}, 1);
-    if constexpr (LAST) epi_tiles(I0{}, I0{}, m0, n0, par);  // first M half (final after phase 6), m-tiles 0, 1
+    if constexpr (LAST) {
+      if (X) epi_tiles(I0{}, I0{}, m0, n0, par);
+    }
     seg_sync_a();
     mfma_quadrant(I1{}, I1{}, F{});
+    if constexpr (LAST) {
+      if (!X) {  // ... m-tiles 2, 3
+        __builtin_amdgcn_sched_barrier(0);
+        epi_tiles(I0{}, I2{}, m0, n0, par);
+      }
+    }
     seg_sync_b();
     // phase 8: (m1, n0)
     read_b(I0{}, 1);
     stage(I0{}, a2, w2, k3, 1);  // A0 of t0 + 3
-    // K-tile t0 + 2 has landed: younger than its last piece are A0 of t0 + 3 (2) and, in a LAST pair, the 4 stores of phase 7
-    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    if constexpr (LAST) epi_tiles(I0{}, I2{}, m0, n0, par);  // ... m-tiles 2, 3
+    // K-tile t0 + 2 has landed: younger than its last piece are A0 of t0 + 3 (2) and, in a LAST pair, the stores issued since
+    // phase 6's staging (X: the 4 of phase 7; Y: all 8)
+    if constexpr (LAST) {
+      if (X) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    if constexpr (LAST) {
+      if (X) epi_tiles(I0{}, I2{}, m0, n0, par);
+    }
     seg_sync_a();
     mfma_quadrant(I1{}, I0{}, F{});
     seg_sync_b();

@@ -182,7 +182,11 @@ VDR_DEV int64_t epi_oct(const GemmK& p, float (&v)[8], float (&u)[8], int64_t m,
   }
   if (E == EPI_BIAS_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    for (int e = 0; e < 8; e += 2) {
+      const f32x2 g = gelu_erf2(f32x2{v[e], v[e + 1]});
+      v[e] = g[0];
+      v[e + 1] = g[1];
+    }
   }
   if (E == EPI_SWIGLU) {
     if (p.bias) {
@@ -505,12 +509,15 @@ VDR_DEV void epilogue_bf16(const GemmK& p, const Acc16& acc, char* stg, int64_t 
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
       bf16x4 o;
+      // (on pairs of neighbouring columns: v_pk_fma_f32 is two values per issue slot, bit for bit the scalar operations)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = acc.t[jt][it][e];
-        v = fmaf(rs, v, fmaf(nrm, csum[jt][e], bias[jt][e]));
-        if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-        o[e] = (bf16_t)v;
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 a2 = {acc.t[jt][it][e], acc.t[jt][it][e + 1]};
+        const f32x2 c2 = {csum[jt][e], csum[jt][e + 1]}, b2 = {bias[jt][e], bias[jt][e + 1]};
+        f32x2 v = __builtin_elementwise_fma(f32x2{rs, rs}, a2, __builtin_elementwise_fma(f32x2{nrm, nrm}, c2, b2));
+        if (EPI == EPI_BIAS_GELU) v = gelu_erf2(v);
+        o[e] = (bf16_t)v[0];
+        o[e + 1] = (bf16_t)v[1];
       }
       const int slot = (2 * jt + (q4 >> 1)) ^ ((row >> 1) & 7);
       *reinterpret_cast<bf16x4*>(stg + row * 128 + slot * 16 + (q4 & 1) * 8) = o;

@@ -619,7 +619,7 @@ bool patch_gather_ok(int in_dtype, int patch, int variant, const void* images) {
 }
 
 #ifndef VDR_GEMM_8P_DEFAULT
-#define VDR_GEMM_8P_DEFAULT 1  // qkv (measured in the forward: qkv 172 -> 147 us per launch; fc1 with its erf-GELU 254 vs ring4 249: stays on ring4)
+#define VDR_GEMM_8P_DEFAULT 3  // qkv + fc1, measured in the forward per launch: qkv 172 -> 147 us; fc1 (erf-GELU) 257 -> 247 once the two wave sets finish a half tile in the same slot (gemm_8p.hip), ViT-L/14@336 fc1 7.62 -> 6.89 ms per step
 #endif
 
 struct LnFold {
@@ -967,7 +967,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, cons, 0, 0, nullptr, nullptr, w.Mp)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, prod, 0, 0, w.x32, w.x32)))
         return rc;
@@ -1001,7 +1001,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
         return rc;
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, xin, xin_bf16, w.h, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.h, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, LnFold(), 0, 0, nullptr, nullptr, w.Mp)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.x, M, D, F, D, EPI_BIAS_RESID, LnFold(), 0, 0, w.x32, w.x32)))
         return rc;
@@ -1010,7 +1010,7 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
       if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, w.h, M, D, D, D, EPI_BIAS_RESID))) return rc;
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.h, 1, w.x, 1, L.n1w, L.n1b, M, identity_map()))) return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1, L.b1, nullptr, nullptr, w.u, M, sw ? 2 * F : F, D, F,
-                     sw ? EPI_SWIGLU : EPI_BIAS_GELU)))
+                     sw ? EPI_SWIGLU : EPI_BIAS_GELU, LnFold(), 0, 0, nullptr, nullptr, w.Mp)))
         return rc;
       if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, L.ls2, w.h, M, D, F, D, EPI_BIAS_RESID))) return rc;
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.h, 1, w.x, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
@@ -1144,10 +1144,12 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
       LnFold cons;
       if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, M, F, D, w, &cons))) return rc;
       cons.colsum = L.s1;
-      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU, cons))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.x, L.w1_f, L.t1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU, cons, 0, 0, nullptr, nullptr, w.Mp))) return rc;
     } else {
       if ((rc = layernorm(m, s, VDR_K_LAYERNORM, w.x, 1, w.hg, 1, L.n2w, L.n2b, M, identity_map()))) return rc;
-      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.hg, L.w1, L.b1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU))) return rc;
+      if ((rc = gemm(m, s, VDR_K_GEMM_FC1, w.hg, L.w1, L.b1, nullptr, nullptr, w.u, M, F, D, F, EPI_BIAS_GELU, LnFold(), 0, 0, nullptr, nullptr,
+                     w.Mp)))
+        return rc;
     }
     if ((rc = gemm(m, s, VDR_K_GEMM_FC2, w.u, L.w2, L.b2, w.x, nullptr, w.x, M, D, F, D, EPI_BIAS_RESID))) return rc;
   }

@@ -72,7 +72,28 @@ VDR_DEV float gelu_erf(float x) {
   q = fmaf(q, a, -4.607286841e-01f);
   q = fmaf(q, a, -1.150403490e+00f);
   q = fmaf(q, a, -1.000050145e+00f);
-  return relu - a * fast_exp2(q);
+  return fmaf(-a, fast_exp2(q), relu);
+}
+
+// The same function on a pair of values, bit for bit (every step is the IEEE operation of the scalar form): the polynomial and
+// the last multiply-add as v_pk_fma_f32 -- two values per issue slot at the scalar instruction's rate
+// (profiles/r03_valu_rate_micro.txt) -- so a pair costs 2 min + 2 max + 7 packed + 2 exp slots instead of 18 + 2 exp.  The
+// GELU epilogues are bound by vector issue.
+VDR_DEV f32x2 gelu_erf2(f32x2 x) {
+  f32x2 a, relu;
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(a[0]) : "v"(x[0]), "v"(5.7f));
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(a[1]) : "v"(x[1]), "v"(5.7f));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(relu[0]) : "v"(x[0]));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(relu[1]) : "v"(x[1]));
+  const auto k = [](float c) { return f32x2{c, c}; };
+  f32x2 q = __builtin_elementwise_fma(k(2.480073296e-05f), a, k(-6.399250922e-04f));
+  q = __builtin_elementwise_fma(q, a, k(7.365777341e-03f));
+  q = __builtin_elementwise_fma(q, a, k(-5.164207073e-02f));
+  q = __builtin_elementwise_fma(q, a, k(-4.607286841e-01f));
+  q = __builtin_elementwise_fma(q, a, k(-1.150403490e+00f));
+  q = __builtin_elementwise_fma(q, a, k(-1.000050145e+00f));
+  const f32x2 e = {fast_exp2(q[0]), fast_exp2(q[1])};
+  return __builtin_elementwise_fma(-a, e, relu);
 }
 
 // One 16-key slice of a softmax row held in the S^T accumulator layout: P = 2^(s * sc + nmb) for the 8 scores of this
