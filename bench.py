@@ -136,6 +136,8 @@ def main():
                     help="with --fp8: the MLP of the CLS rows on the bf16 weights (vdr_config.fp8_cls_bf16)")
     ap.add_argument("--resid-fp32", action="store_true",
                     help="vdr_config.resid_fp32 = 1: fp32 master copy of the residual stream (bf16 path; parity option, costs traffic)")
+    ap.add_argument("--ln-fin-fused", action="store_true",
+                    help="vdr_config.ln_fin_fused = 1: the LayerNorm fold's row statistics finalised inside the residual GEMMs instead of by their own launches (A/B: same bits, same time)")
     ap.add_argument("--out", choices=["cls", "dense"], default="cls",
                     help="cls: [N, D] CLS features (headline); dense: [N, n*D] per-patch descriptors (BASELINE config 4)")
     ap.add_argument("--input", choices=["bf16", "fp32"], default="bf16",
@@ -207,7 +209,8 @@ def main():
         ocfg = vo.CONFIGS[a.model]
         weights = vo.make_weights(ocfg, seed=1)
     model = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
-                           full_last_block=a.full_last_block, fp8_cls_bf16=a.fp8_cls_bf16, resid_fp32=a.resid_fp32)
+                           full_last_block=a.full_last_block, fp8_cls_bf16=a.fp8_cls_bf16, resid_fp32=a.resid_fp32,
+                           ln_fin_fused=a.ln_fin_fused)
     eng = model.engine
     B, D = a.batch, ocfg.dim
     g = torch.Generator().manual_seed(1000 + rank)
@@ -313,7 +316,8 @@ def main():
     if not a.full_last_block and not sam and not dense and world == 1:
         try:
             mf = vdr.load_model(a.model, weights=weights, device=dev, micro_batch=a.micro_batch, streams=a.streams, fp8=a.fp8,
-                                full_last_block=True, fp8_cls_bf16=a.fp8_cls_bf16, resid_fp32=a.resid_fp32)
+                                full_last_block=True, fp8_cls_bf16=a.fp8_cls_bf16, resid_fp32=a.resid_fp32,
+                                ln_fin_fused=a.ln_fin_fused)
             ref = torch.empty_like(mine)
             for _ in range(max(a.warmup, 2)):
                 mf.engine.forward_into(images, ref, vdr.OUT_CLS)
@@ -417,7 +421,7 @@ def main():
                                       + (", all-gather of feature matrix" if world > 1 else ""),
                           "global_batch": total, "parallelism": f"batch-shard dp{world}",
                           "weights": "random-init (seed 1)", "input_dtype": "fp32" if (sam or a.input == "fp32") else "bf16", "micro_batch": a.micro_batch, "streams": a.streams,
-                          "fp8_cls_bf16": bool(a.fp8_cls_bf16), "resid_fp32": bool(a.resid_fp32),
+                          "fp8_cls_bf16": bool(a.fp8_cls_bf16), "resid_fp32": bool(a.resid_fp32), "ln_fin_fused": bool(a.ln_fin_fused),
                           "last_block": "every token" if (a.full_last_block or sam or dense) else
                                         "attention on every token; out-projection / norm2 / MLP on the CLS rows only (bitwise the same features)"},
                "feature_GBps": round(total * D * feats.element_size() * a.steps / dt / 1e9, 4),

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define VDR_ABI_VERSION 7
+#define VDR_ABI_VERSION 8
 
 typedef enum {
   VDR_OK = 0,
@@ -135,6 +135,13 @@ typedef struct {
                       /* 1.2e-2 / 1.7e-2 at 12 / 24 / 40 blocks, against 5.8e-3 / 6.6e-3 / 1.0e-2 with this switch                 */
                       /* (tools/resid_precision.py; SURVEY 8d states 1e-2).  Costs 8 more bytes per element of HBM traffic in     */
                       /* the out-projection and fc2 launches.                                                                     */
+  int32_t ln_fin_fused; /* LayerNorm fold: where the (sum, sumsq) partials a residual GEMM leaves become (mean, rstd) for a   */
+                      /* consumer that reads finalised statistics (large launches).  0 (default): a small ln_finalize launch  */
+                      /* between the out-projection / fc2 and the qkv / fc1; 1: inside the residual GEMM -- the workgroup     */
+                      /* that adds the last partial to a block of rows finalises the block (ring4 tile variants), no launch.  */
+                      /* Same arithmetic: the features are bitwise equal.  Measured equal in time too (ViT-B batch 256: 8.73  */
+                      /* vs 8.71-8.74 ms; ViT-L/14@336 batch 64: 25.96 vs 25.99 ms): the counter's round trip at the end of   */
+                      /* every tile costs the residual GEMMs what the 23 launches cost, so the simpler form is the default.   */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;

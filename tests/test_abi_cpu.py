@@ -26,13 +26,13 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()  # raises if the .so or any symbol is missing
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.vdr_abi_version() == 7
+    assert lib.vdr_abi_version() == 8
     assert lib.vdr_kernel_class_name(4) == b"attention"
 
 
 def test_config_struct_layout_matches_header():
     from vdr import _lib
-    assert C.sizeof(_lib.vdr_config) == 4 * 24  # 23 int32 fields + one float
+    assert C.sizeof(_lib.vdr_config) == 4 * 25  # 24 int32 fields + one float
 
 
 def test_invalid_configs_are_rejected_before_touching_a_device():

@@ -36,13 +36,14 @@ def _min_cos(a, b):
     return torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
 
 
-def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True, full_last_block=False, fp8_cls_bf16=False, resid_fp32=False):
+def _engine(cfg: vo.VitCfg, w, micro_batch=0, fp8=0, ln_fold=True, full_last_block=False, fp8_cls_bf16=False, resid_fp32=False,
+            ln_fin_fused=False):
     import vdr
     vc = vdr.VdrConfig(img=cfg.img, patch=cfg.patch, in_chans=cfg.in_chans, dim=cfg.dim, heads=cfg.heads, layers=cfg.layers,
                        mlp_hidden=cfg.mlp_hidden, act=cfg.act, pre_ln=cfg.pre_ln, layerscale=cfg.layerscale,
                        has_cls=cfg.has_cls, has_pos=cfg.has_pos, input_ln=cfg.input_ln, ln_eps=cfg.ln_eps,
                        micro_batch=micro_batch, fp8=fp8, ln_fold=ln_fold, full_last_block=full_last_block,
-                       fp8_cls_bf16=fp8_cls_bf16, resid_fp32=resid_fp32)
+                       fp8_cls_bf16=fp8_cls_bf16, resid_fp32=resid_fp32, ln_fin_fused=ln_fin_fused)
     e = vdr.Engine(vc)
     e.load_weights(w)
     return e
@@ -683,6 +684,9 @@ def test_full_batch_properties_at_baseline_size():
     assert torch.equal(out_p, out[perm])
     small = e.forward(x[100:103], vdr.OUT_CLS)
     assert torch.equal(small, out[100:103])
+    # the LayerNorm statistics finalised inside the persistent residual GEMMs (1182 tiles on 512 workgroups, three tile
+    # columns per block of rows) instead of by their own launches: the same bits
+    assert torch.equal(_engine(cfg, w, ln_fin_fused=True).forward(x, vdr.OUT_CLS), out)
     # The qkv linears of these launches run on tile variant 31 (csrc/gemm_8p.hip: 256-row tiles, one workgroup per CU), those
     # of the 3-image run on the ring4 tiles: the comparison above is 8-phase == ring4 bit for bit, LayerNorm fold included.
     # A batch whose token count is NOT a multiple of 256 (100 images = 19700 rows: 693 tiles, the last row tile 244 rows):
@@ -693,6 +697,42 @@ def test_full_batch_properties_at_baseline_size():
         assert torch.isfinite(big.float()).all()
         for lo in (0, 47, 97):
             assert torch.equal(ef.forward(x[lo:lo + 3].contiguous(), vdr.OUT_TOKENS), big[lo:lo + 3]), (fold, lo)
+
+
+@pytest.mark.parametrize("name,batch", [("p16_d128", 5), ("p14_d192", 3), ("dinov2_swiglu_ls", 4), ("vit_base16_224", 40),
+                                        ("vit_base16_224", 100)])
+@pytest.mark.parametrize("resid_fp32", [False, True])
+def test_layernorm_statistics_finalised_inside_the_residual_gemm(name, batch, resid_fp32):
+    """vdr_config.ln_fin_fused = 1: the workgroup of the out-projection / fc2 GEMM that adds the LAST partial
+    sums to a block of rows turns them into (mean, rstd) itself (csrc/gemm_kernels.h finalize_rows_if_last: agent-scope
+    stores and loads of the partials, one counter per block of tile rows) -- no ln_finalize launch between a residual GEMM
+    and the qkv / fc1 that folds LayerNorm (norm1 / norm2 of the frozen ViTs called at tfds_dense_descriptor.py:123).  Same
+    arithmetic as the separate launch (the default): every output bit for bit, small launches (128 x 128 ring4 tiles, a handful of
+    workgroups) and large ones (persistent 128 x 256 tiles on every CU, three tile columns per block of rows racing for
+    the counter; ViT-B at 40 / 100 images), CLS tail and full last block, run twice (the counters must come back to zero)."""
+    import vdr
+    cfg = SMALL[name] if name in SMALL else vo.CONFIGS[name]
+    w = vo.make_weights(cfg, seed=71, scale=0.05) if name in SMALL else vo.make_weights(cfg, seed=71)
+    g = torch.Generator().manual_seed(72)
+    x = torch.rand(batch, cfg.in_chans, cfg.img, cfg.img, generator=g).to(torch.bfloat16).cuda()
+    for full in (False, True):
+        a = _engine(cfg, w, resid_fp32=resid_fp32, full_last_block=full, ln_fin_fused=True)
+        b = _engine(cfg, w, resid_fp32=resid_fp32, full_last_block=full)
+        for mode in (vdr.OUT_CLS, vdr.OUT_TOKENS):
+            want = b.forward(x, mode)
+            assert torch.isfinite(want.float()).all()
+            for rep in range(2):
+                assert torch.equal(a.forward(x, mode), want), (name, full, mode, rep)
+    if name == "vit_base16_224" and batch == 100:
+        # the profiler sees the difference (launches large enough for the 8-phase qkv / fc1, which read finalised statistics):
+        # one ln_finalize launch per forward -- the statistics of the assembled tokens -- instead of two per block
+        counts = []
+        for e in (_engine(cfg, w, resid_fp32=resid_fp32, ln_fin_fused=True), _engine(cfg, w, resid_fp32=resid_fp32)):
+            e.profile(True)
+            e.forward(x, vdr.OUT_TOKENS)
+            counts.append(e.profile_read().get("layernorm", {}).get("launches", 0))
+            e.profile(False)
+        assert counts == [1, 2 * cfg.layers], counts
 
 
 # ---- SAM / MedSAM image encoder (the reference's default backbone, SURVEY.md §8 row f-1) ----------------

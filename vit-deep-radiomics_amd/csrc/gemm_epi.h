@@ -48,6 +48,12 @@ struct GemmK {
   int ln_fold = 0;  // the consumer-side fold is on (statistics from ln_stats or from ln_cpart)
   float* ln_part;
   int64_t part_stride;
+  // the last workgroup to add its partial sums to a block of tile rows finalises that block's (mean, rstd) (ring4 kernels,
+  // residual epilogue; finalize_rows_if_last in gemm_kernels.h); null = off
+  float* fin_stats = nullptr;
+  uint32_t* fin_cnt = nullptr;
+  int fin_groups = 0;
+  float fin_inv_d = 0.0f, fin_eps = 0.0f;
   int a_rpg;
   int64_t a_gs, a_is;
   int out_f32;
@@ -733,9 +739,11 @@ VDR_DEV void epilogue_resid_impl(const GemmK& p, const AccT& acc, char* stg, int
           a += dpp_row_shl<1>(a);
           b += dpp_row_shl<1>(b);
           if (c8 == 0 && om[k] >= 0) {
+            // (agent-scope stores: written through to where a workgroup on another XCD reads them -- the one that finalises
+            // this block of rows, finalize_rows_if_last -- instead of staying in this XCD's L2 until the kernel ends)
             float* dst = p.ln_part + ((int64_t)((n_base + jp * 64) >> 6) * p.part_stride + om[k]) * 2;
-            dst[0] = a;
-            dst[1] = b;
+            __hip_atomic_store(dst, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }

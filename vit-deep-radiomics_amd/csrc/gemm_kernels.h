@@ -655,6 +655,59 @@ VDR_DEV void gemm_ring4_body(const GemmK& p, const int64_t m0, const int n0, cha
 #undef VDR_GSTAMP
 }
 
+// Producer-side finalisation of the LayerNorm statistics (GemmK::fin_stats; residual epilogue of the ring4 kernels).  A block
+// of BM tile rows gets its (sum, sumsq) partials from tiles_n workgroups -- one per tile column -- wherever on the chip they
+// run.  Each of them, after its own partial stores are acknowledged (agent-scope stores in epilogue_resid_impl, counted out
+// by vmcnt(0)), bumps the block's counter; the one that sees tiles_n - 1 is the last, reads all partials of the block's rows
+// back with agent-scope loads, writes (mean, rstd) -- ln_finalize_kernel's arithmetic: double, groups in order, so the
+// statistics are bitwise those of the separate launch -- and zeroes the counter for the next launch.  No fence: a release
+// fence at agent scope writes the XCD's whole L2 back (measured on a stream-K hand-off: fc2 214 -> 298 us).
+// Takes the ln_finalize launch between a residual GEMM and the fold's consumer away (23 launches, 0.15 ms by the profiler in
+// the headline step) -- and measures EQUAL in the forward (8.73 vs 8.71-8.74 ms; ViT-L/14@336 25.96 vs 25.99): the wait for the
+// stores' acknowledgement and the counter's round trip stand at the end of every tile of every workgroup.  Hence an option
+// (vdr_config.ln_fin_fused), off by default.
+template <int BM>
+VDR_DEV void finalize_rows_if_last(const GemmK& q, int tm, char* smem) {
+  if (!q.fin_stats) return;  // (kernel argument: uniform)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // every thread's partial stores are out; the staging area is read out
+  if (threadIdx.x == 0) {
+    const uint32_t seen = __hip_atomic_fetch_add(q.fin_cnt + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<volatile uint32_t*>(smem) = seen;
+  }
+  __syncthreads();
+  const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(smem);
+  if (seen + 1 == (uint32_t)q.tiles_n) {
+    const int64_t row = (int64_t)tm * BM + threadIdx.x;
+    if ((int)threadIdx.x < BM && row < q.M) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int g0 = 0; g0 < q.fin_groups; g0 += 16) {
+        uint64_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {  // 16 independent loads in flight
+          const int g = g0 + j < q.fin_groups ? g0 + j : q.fin_groups - 1;
+          v[j] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(q.ln_part + ((int64_t)g * q.part_stride + row) * 2),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (g0 + j < q.fin_groups) {
+            s1 += (double)__uint_as_float((uint32_t)v[j]);
+            s2 += (double)__uint_as_float((uint32_t)(v[j] >> 32));
+          }
+      }
+      const double mean = s1 * (double)q.fin_inv_d;
+      double var = s2 * (double)q.fin_inv_d - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      float2 o;
+      o.x = (float)mean;
+      o.y = (float)(1.0 / sqrt(var + (double)q.fin_eps));
+      *reinterpret_cast<float2*>(q.fin_stats + row * 2) = o;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(q.fin_cnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // TAG: no effect on the code -- a second symbol for the same instantiation, so that a profile separates the two residual
 // GEMMs of a block (TAG 1 = K > N: fc2; TAG 0: the out-projection and everything else)
 template <int WAVES_M, int WAVES_N, int EPI, int TAG = 0>
@@ -664,6 +717,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4_kernel(Ge
   int tm, tn;
   tile_of(p, wg, tm, tn);
   gemm_ring4_body<WAVES_M, WAVES_N, EPI>(p, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
+  if constexpr (epi_base(EPI) == EPI_BIAS_RESID) finalize_rows_if_last<WAVES_M * 64>(p, tm, smem);
 }
 
 // Persistent form of ring4: as many workgroups as the chip holds at once (two per CU), each walking the tile list with
@@ -712,6 +766,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(G
       VDR_GLOBAL(colsum);
       VDR_GLOBAL(ln_cpart);
       VDR_GLOBAL(ln_part);
+      VDR_GLOBAL(fin_stats);
+      VDR_GLOBAL(fin_cnt);
       VDR_GLOBAL(sA);
       VDR_GLOBAL(sW);
       VDR_GLOBAL(sC);
@@ -724,6 +780,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 4) void gemm_ring4p_kernel(G
     int tm, tn;
     tile_of(q, wg, tm, tn);
     gemm_ring4_body<WAVES_M, WAVES_N, EPI, true>(q, (int64_t)tm * (WAVES_M * 64), tn * (WAVES_N * 64), smem);
+    if constexpr (epi_base(EPI) == EPI_BIAS_RESID) finalize_rows_if_last<WAVES_M * 64>(q, tm, smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is read out: the next tile's ring fill may overwrite it
     __syncthreads();
   }
@@ -847,6 +904,14 @@ static hipError_t launch_cfg(const GemmArgs& a, int epi, hipStream_t s) {
   k.ln_part = a.ln_part;
   k.part_stride = a.part_stride;
   k.ln_fold = a.ln_stats || a.ln_cpart;
+  if (a.fin_stats) {  // producer-side finalisation: ring4 kernels, residual epilogue, rows stored where they are computed
+    if (PIPE < 50 || epi_base(epi) != EPI_BIAS_RESID || !a.ln_part || !a.fin_cnt || a.win_ws || (a.N & 63)) return hipErrorInvalidValue;
+    k.fin_stats = a.fin_stats;
+    k.fin_cnt = a.fin_cnt;
+    k.fin_groups = a.N / 64;
+    k.fin_inv_d = a.fin_inv_d;
+    k.fin_eps = a.fin_eps;
+  }
   if (a.ldc >= ((int64_t)1 << 24)) return hipErrorInvalidValue;  // (epilogue_bf16 addresses a wave tile with 32-bit byte offsets)
   // (the residual epilogue, epilogue_resid: bf16 in place or out of place, no consumer-side fold, 32-bit row numbers)
   if (epi_base(epi) == EPI_BIAS_RESID && (k.ln_fold || a.out_f32 || a.M >= ((int64_t)1 << 31))) return hipErrorInvalidValue;

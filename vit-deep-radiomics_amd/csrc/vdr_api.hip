@@ -69,6 +69,8 @@ struct LayerW {
   float *sqkv = nullptr, *tqkv = nullptr, *s1 = nullptr, *t1 = nullptr;
 };
 
+constexpr int FIN_ROWS = 1 << 16;  // finalisation counters per stream: blocks of >= 64 tile rows, i.e. launches of up to 4 M rows
+
 struct ProfEvent {
   int cls;
   hipEvent_t a, b;
@@ -103,6 +105,11 @@ struct vdr_model {
   std::vector<hipStream_t> aux;
   std::vector<hipEvent_t> aux_fork, aux_join;
   int cur_aux = 0;  // index of the stream run_blocks is being called for (set by the forward's micro-batch loop)
+  // producer-side LayerNorm finalisation (GemmArgs::fin_stats): zeroed counters, one per block of tile rows and per stream
+  // a forward can run on (FIN_ROWS each; the kernels leave them zeroed); stats_fresh: the (mean, rstd) buffer of the
+  // workspace in use already holds the statistics of the stream's current contents (set by gemm(), taken by ln_consumer())
+  uint32_t* fin_cnt = nullptr;
+  bool stats_fresh = false;
   // profiler
   bool prof = false;
   uint32_t prof_mask = 0xffffffffu;
@@ -422,6 +429,11 @@ int resolve(vdr_model* m) {
     }
     VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
+  if (!m->fin_cnt) {
+    VDR_TRY(hipMalloc(&m->fin_cnt, (size_t)8 * FIN_ROWS * 4), "hipMalloc(LayerNorm finalisation counters)");
+    VDR_TRY(hipMemset(m->fin_cnt, 0, (size_t)8 * FIN_ROWS * 4), "hipMemset");
+    VDR_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  }
   for (auto& sl : m->slots) std::vector<float>().swap(sl.host);  // host copies are no longer needed
   m->resolved = true;
   return VDR_OK;
@@ -631,6 +643,7 @@ struct LnFold {
   int groups = 0;
   int64_t cstride = 0;
   float inv_d = 0.0f, eps = 0.0f;
+  float* fin_stats = nullptr;     // producer: finalise the statistics of the rows it completes here (see finalize_rows_if_last)
 };
 
 // which GEMM classes take tile variant 31 when the launch is eligible (gemm_8p_eligible): measured per class in the
@@ -669,10 +682,14 @@ int ln_consumer(vdr_model* m, hipStream_t s, int cls, int64_t M, int N, int D, c
     cons->cstride = w.Mp;
     cons->inv_d = 1.0f / (float)D;
     cons->eps = m->cfg.ln_eps;
+    m->stats_fresh = false;
     return VDR_OK;
   }
-  Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
-  VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, m->cfg.ln_eps, s), "ln_finalize");
+  if (!m->stats_fresh) {  // (otherwise the residual GEMM that wrote the stream finalised its rows' statistics itself)
+    Scope sc(m, s, VDR_K_LAYERNORM, 0.0, (double)M * (groups + 1) * 8);
+    VDR_TRY(launch_ln_finalize(w.part, groups, w.Mp, w.stats, M, D, m->cfg.ln_eps, s), "ln_finalize");
+  }
+  m->stats_fresh = false;
   cons->cpart = nullptr;
   cons->stats = w.stats;
   return VDR_OK;
@@ -721,7 +738,20 @@ int gemm(vdr_model* m, hipStream_t s, int cls, const void* A, const void* W, con
       return VDR_OK;
     }
   }
-  VDR_TRY(launch_gemm_w(m, g, epi, gemm_variant_for(cls, g.M, N), s), "gemm");
+  const int variant = gemm_variant_for(cls, g.M, N);
+  // a producer of LayerNorm partials on a ring4 tile variant also finalises them (finalize_rows_if_last): the consumer's
+  // ln_finalize launch is not needed then (ln_consumer takes m->stats_fresh)
+  bool fin = false;
+  if (ln.fin_stats && ln.part && m->fin_cnt && m->cfg.ln_fin_fused && variant >= 26 && variant <= 29 && epi == EPI_BIAS_RESID &&
+      (g.M + 63) / 64 <= FIN_ROWS) {
+    g.fin_stats = ln.fin_stats;
+    g.fin_cnt = m->fin_cnt + (size_t)m->cur_aux * FIN_ROWS;
+    g.fin_inv_d = 1.0f / (float)N;
+    g.fin_eps = m->cfg.ln_eps;
+    fin = true;
+  }
+  VDR_TRY(launch_gemm_w(m, g, epi, variant, s), "gemm");
+  if (ln.part) m->stats_fresh = fin;
   return VDR_OK;
 }
 
@@ -855,6 +885,7 @@ int block_tail_cls(vdr_model* m, hipStream_t s, const Carve& w, const LayerW& L,
     LnFold prod, cons;
     prod.part = w.part;
     prod.part_stride = w.Mp;
+    prod.fin_stats = w.stats;
     if ((rc = gemm(m, s, VDR_K_GEMM_PROJ, w.o, L.wproj, L.bproj, w.x, L.ls1, xc, mb, D, D, D, EPI_BIAS_RESID, prod, stride, stride, r32, c32)))
       return rc;
     if ((rc = ln_consumer(m, s, VDR_K_GEMM_FC1, mb, sw ? 2 * F : F, D, w, &cons))) return rc;
@@ -945,6 +976,10 @@ int run_blocks(vdr_model* m, hipStream_t s, const Carve& w, int mb, int ntok, co
     LnFold prod;
     prod.part = w.part;
     prod.part_stride = w.Mp;
+    // (the producers finalise the statistics where a consumer reads finalised ones; launches small enough for the ring3 /
+    // ring4 consumers to finalise their own rows from the partials need nothing)
+    if (!ln_stats_in_gemm(VDR_K_GEMM_QKV, M, 3 * D, D / 64) || !ln_stats_in_gemm(VDR_K_GEMM_FC1, M, sw ? 2 * F : F, D / 64))
+      prod.fin_stats = w.stats;
     for (int i = 0; i < c.layers; ++i) {
       const LayerW& L = m->layers[i];
       LnFold cons;
@@ -1126,6 +1161,7 @@ int run_sam(vdr_model* m, hipStream_t s, const Carve& w, int mb, int out_dtype, 
       }
       Scope sc(m, s, VDR_K_GEMM_PROJ, 2.0 * T * D * D, 2.0 * ((double)T * D + (double)D * D + 2.0 * M * D));
       VDR_TRY(launch_gemm_w(m, ga, EPI_BIAS_RESID, gemm_variant_for(VDR_K_GEMM_PROJ, ga.M, ga.N), s), "proj gemm");
+      m->stats_fresh = false;  // (window un-partition scatters the rows: their statistics are finalised by ln_consumer's launch)
     }
     if (fp8) {
       {
@@ -1315,6 +1351,7 @@ void vdr_destroy(vdr_handle h) {
   }
   for (auto& kv : h->w_il)
     if (kv.second) hipFree(kv.second);
+  if (h->fin_cnt) hipFree(h->fin_cnt);
   for (auto st : h->streams) hipStreamDestroy(st);
   for (auto st : h->aux) hipStreamDestroy(st);
   for (auto e : h->aux_fork) hipEventDestroy(e);
@@ -1473,6 +1510,7 @@ int vdr_forward(vdr_handle m, const void* images, int in_dtype, int batch, void*
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
     const int si = chunk % ns;
     m->cur_aux = si;
+    m->stats_fresh = false;  // (nothing has finalised the statistics of this micro-batch yet)
     hipStream_t s = ns == 1 ? caller : m->streams[si];
     const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* img = (const char*)images + (size_t)b0 * img_elems * in_es;
@@ -1599,6 +1637,7 @@ static int forward_tokens_impl(vdr_handle m, const void* tokens, int in_dtype, i
     const int mb = batch - b0 < mb_max ? batch - b0 : mb_max;
     const int si = chunk % ns;
     m->cur_aux = si;
+    m->stats_fresh = false;  // (nothing has finalised the statistics of this micro-batch yet)
     hipStream_t s = ns == 1 ? caller : m->streams[si];
     const Carve w = carve(m, (char*)workspace + si * per_ws, mb_max, ntok);
     const char* tok = (const char*)tokens + (size_t)b0 * seq * D * in_es;

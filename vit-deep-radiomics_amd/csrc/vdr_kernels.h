@@ -80,6 +80,12 @@ struct GemmArgs {
   int ln_groups = 0;
   int64_t ln_cstride = 0;
   float ln_inv_d = 0.0f, ln_eps = 0.0f;
+  // producer side, ring4 tile variants with the residual epilogue: the workgroup that stores the LAST partial sums of a
+  // block of tile rows turns them into (mean, rstd) at fin_stats [M][2] -- ln_finalize_kernel's arithmetic, no launch.
+  // fin_cnt: one zeroed counter per tile row (left zeroed); the partials span fin_groups = N / 64 groups
+  float* fin_stats = nullptr;
+  uint32_t* fin_cnt = nullptr;
+  float fin_inv_d = 0.0f, fin_eps = 0.0f;
   //   producer side: per output row and 64-column group, (sum, sum of squares) of the bf16 outputs
   float* ln_part = nullptr;         // [N/64][part_stride][2] fp32 or null
   int64_t part_stride = 0;

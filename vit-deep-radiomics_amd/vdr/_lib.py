@@ -28,7 +28,8 @@ class vdr_config(C.Structure):
                 ("input_ln", C.c_int32), ("ln_eps", C.c_float), ("micro_batch", C.c_int32),
                 ("streams", C.c_int32), ("window", C.c_int32),
                 ("global_mask", C.c_int32), ("neck_chans", C.c_int32), ("fp8", C.c_int32), ("no_ln_fold", C.c_int32),
-                ("full_last_block", C.c_int32), ("fp8_cls_bf16", C.c_int32), ("resid_fp32", C.c_int32)]
+                ("full_last_block", C.c_int32), ("fp8_cls_bf16", C.c_int32), ("resid_fp32", C.c_int32),
+                ("ln_fin_fused", C.c_int32)]
 
 
 # every symbol include/vdr.h declares: name -> (restype, argtypes)
@@ -94,7 +95,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.vdr_abi_version() != 7:
+    if lib.vdr_abi_version() != 8:
         raise ImportError("libvdr ABI version mismatch")
     _lib = lib
     return lib

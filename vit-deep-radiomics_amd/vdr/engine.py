@@ -39,6 +39,7 @@ class VdrConfig:
                                # the same features bit for bit; see vdr_config.full_last_block)
     fp8_cls_bf16: bool = False  # fp8 = 1: the MLP of the CLS rows on the bf16 weights (vdr_config.fp8_cls_bf16)
     resid_fp32: bool = False  # bf16 path: fp32 master copy of the residual stream (vdr_config.resid_fp32)
+    ln_fin_fused: bool = False  # LayerNorm fold: the residual GEMMs finalise the row statistics themselves (vdr_config.ln_fin_fused)
 
     @property
     def n_patches(self):
@@ -63,6 +64,7 @@ class VdrConfig:
         c.full_last_block = int(self.full_last_block)
         c.fp8_cls_bf16 = int(self.fp8_cls_bf16)
         c.resid_fp32 = int(self.resid_fp32)
+        c.ln_fin_fused = int(self.ln_fin_fused)
         return c
 
 

@@ -96,7 +96,7 @@ class VitDescriptorModel:
 
 def load_model(model_name: str, model_path=None, weights=None, device=None, micro_batch: int = 0, streams: int = 0,
                fp8: int = 0, full_last_block: bool = False, ln_fold: bool = True, fp8_cls_bf16: bool = False,
-               resid_fp32: bool = False):
+               resid_fp32: bool = False, ln_fin_fused: bool = False):
     """R1.  model_name: 'dinov2' | 'medsam' (reference names) or any key of ARCHS.
     model_path: a PyTorch state_dict file with the canonical key names; loaded with
     torch.load(weights_only=True).  weights: the same dict passed directly.
@@ -104,12 +104,14 @@ def load_model(model_name: str, model_path=None, weights=None, device=None, micr
     (BASELINE config 5; pre-LN models).  full_last_block=True: `model(x)` computes every token of the last block
     like the reference does before it keeps x[:, 0] (default: the CLS rows only, same bits).  fp8_cls_bf16=True (fp8 models
     with a CLS token): the MLP of the CLS rows runs on the bf16 weights (vdr_config.fp8_cls_bf16).  resid_fp32=True: the
-    residual stream keeps an fp32 master copy (vdr_config.resid_fp32; bf16 path of the plain ViTs)."""
+    residual stream keeps an fp32 master copy (vdr_config.resid_fp32; bf16 path of the plain ViTs).  ln_fin_fused=True:
+    the LayerNorm fold's row statistics are finalised inside the residual GEMMs instead of by a launch of their own (A/B)."""
     if model_name not in ARCHS:
         raise KeyError(f"unknown model_name {model_name!r}; known: {sorted(ARCHS)} + 'medsam'")
     cfg = VdrConfig(**{**ARCHS[model_name].__dict__, "micro_batch": micro_batch, "streams": streams,
                        "fp8": int(fp8) or int(ARCHS[model_name].fp8), "full_last_block": bool(full_last_block),
-                       "ln_fold": bool(ln_fold), "fp8_cls_bf16": bool(fp8_cls_bf16), "resid_fp32": bool(resid_fp32)})
+                       "ln_fold": bool(ln_fold), "fp8_cls_bf16": bool(fp8_cls_bf16), "resid_fp32": bool(resid_fp32),
+                       "ln_fin_fused": bool(ln_fin_fused)})
     if weights is None:
         if model_path is None:
             raise ValueError("load_model needs model_path or weights (no network: nothing is downloaded)")
