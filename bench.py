@@ -382,7 +382,7 @@ def main():
         traffic, traffic_note = None, "profiles/r04_pmc_traffic.txt"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
-            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU)", "gemm_qkv": "gemm_qkv (EPI_BIAS, 8-phase)", "attention": "attention",
+            key = {"gemm_fc1": "gemm_fc1 (EPI_BIAS_GELU, 8-phase)", "gemm_qkv": "gemm_qkv (EPI_BIAS, 8-phase)", "attention": "attention",
                    "gemm_fc2": "gemm_fc2 (EPI_BIAS_RESID, K > N)", "gemm_proj": "gemm_proj (EPI_BIAS_RESID, K = N)"}.get(dom)
             if pm.get("_source_id") != vdr.source_id():
                 traffic_note = f"dropped: profiles/r04_pmc_traffic.json was taken with kernel sources {pm.get('_source_id')}, this run has {vdr.source_id()}"

@@ -8,8 +8,9 @@ import sys
 from collections import defaultdict
 
 CLASSES = [  # (label, regex on the demangled kernel name: gemm_ring4[p]_kernel<WAVES_M, WAVES_N, EPI, TAG>; TAG 1 = K > N;
-    # gemm_8p_kernel<EPI, FOLD> = tile variant 31, the default of the qkv launches since round 4)
+    # gemm_8p_kernel<EPI, FOLD> = tile variant 31, the default of the qkv and fc1 launches since round 4)
     ("gemm_qkv (EPI_BIAS, 8-phase)", r"gemm_8p_kernel<\(?(vdr::)?(Epilogue)?\)?0, "),
+    ("gemm_fc1 (EPI_BIAS_GELU, 8-phase)", r"gemm_8p_kernel<\(?(vdr::)?(Epilogue)?\)?1, "),
     ("gemm_fc1 (EPI_BIAS_GELU)", r"gemm_ring\dp?_kernel<\d+, \d+, 1, \d+>"),
     ("gemm_proj (EPI_BIAS_RESID, K = N)", r"gemm_ring\dp?_kernel<\d+, \d+, 2, 0>"),
     ("gemm_fc2 (EPI_BIAS_RESID, K > N)", r"gemm_ring\dp?_kernel<\d+, \d+, 2, 1>"),
@@ -22,6 +23,7 @@ M = 50432
 ALG = {"gemm_fc1 (EPI_BIAS_GELU)": (M * 768 + 3072 * 768 + M * 3072) * 2 / 1e6,
        "gemm_qkv (EPI_BIAS)": (M * 768 + 2304 * 768 + M * 2304) * 2 / 1e6,
        "gemm_qkv (EPI_BIAS, 8-phase)": (M * 768 + 2304 * 768 + M * 2304) * 2 / 1e6,
+       "gemm_fc1 (EPI_BIAS_GELU, 8-phase)": (M * 768 + 3072 * 768 + M * 3072) * 2 / 1e6,
        "gemm_proj (EPI_BIAS_RESID, K = N)": (M * 768 + 768 * 768 + 2 * M * 768) * 2 / 1e6,   # A + W + residual in + out
        "gemm_fc2 (EPI_BIAS_RESID, K > N)": (M * 3072 + 768 * 3072 + 2 * M * 768) * 2 / 1e6,
        "attention": (M * 2304 + M * 768) * 2 / 1e6}

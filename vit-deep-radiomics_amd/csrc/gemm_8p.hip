@@ -112,6 +112,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
   };
 
   // ---- tile list: workgroups of one XCD (id % 8) take neighbouring tiles (they share A row panels in that L2) ----
+  // Row-major on purpose.  PMC (profiles/r04_pmc_traffic.txt): fc1 reads 453 MB per launch against 82 MB of operands -- every
+  // XCD streams all of W (4.7 MB) once per round of 32 tiles.  Walking column groups of 3 / 4 / 6 tile columns instead
+  // (an XCD's 32 tiles = 8 tile rows x 4 columns: W traffic down 9 x) measured SLOWER in the forward: qkv 1.79 -> 1.88 / 1.83
+  // / 1.82 ms per step, fc1 2.50 -> 2.51 / 2.55 / 2.50 -- the L2 misses are not what the loop waits for.
   const int nwg = gridDim.x;
   const int vid = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
   auto tile_bases = [&](int L, const char*& a, const char*& w, int& m0, int& n0) {
@@ -442,7 +446,9 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(G8 p) {
 
 // whether tile variant 31 takes this launch (and is expected to pay: many tiles, a write-once bf16 output)
 // the tile-count rule alone: one workgroup per CU walks tiles / CUs rounds -- at least two, and the last one reasonably full
-// (a 2.3-round launch runs 3 rounds long: measured on ViT-g/14's qkv, 594 tiles: 114 us against ring4's 107)
+// (a 2.3-round launch runs 3 rounds long: measured on ViT-g/14's qkv, 594 tiles: 114 us against ring4's 107; a launch of
+// less than one round -- one MedSAM slice, M = 4096: 144 / 192 tiles -- pays the pipeline fill and the four epilogue slots once
+// per 12 K-tiles: qkv 27.1 -> 28.9 us, fc1 31.4 -> 32.4 against the 128-row ring4 tiles)
 bool gemm_8p_shape_ok(int64_t M, int N) {
   if (M <= 0 || (N & 255)) return false;
   int n_cu = device_cu_count(current_device_index());
