@@ -142,6 +142,7 @@ typedef struct {
                       /* Same arithmetic: the features are bitwise equal.  Measured equal in time too (ViT-B batch 256: 8.73  */
                       /* vs 8.71-8.74 ms; ViT-L/14@336 batch 64: 25.96 vs 25.99 ms): the counter's round trip at the end of   */
                       /* every tile costs the residual GEMMs what the 23 launches cost, so the simpler form is the default.   */
+                      /* (The counters live in the handle, like its internal streams: one forward at a time per handle.)      */
 } vdr_config;
 
 typedef struct vdr_model* vdr_handle;
