@@ -115,3 +115,23 @@ def test_no_asm_memory_instruction_reads_an_sgpr_a_valu_has_just_written():
         total += n
         assert not hits, hits[:3]
     assert total > 0
+
+
+def test_8phase_kernels_have_no_vector_memory_instruction_their_counted_waits_do_not_know():
+    """csrc/gemm_8p.hip waits with COUNTED `s_waitcnt vmcnt(n)` for the LDS-DMA piece a phase needs -- loads, LDS-DMA pieces and
+    stores retire one counter in issue order, so every count in the source is exact only while the kernel issues no vector-memory
+    instruction the source does not show: no scratch (a spill reload is a load), no plain global load.  The four instantiations
+    are compiled to ISA: scratch size 0, and every vector-memory instruction is an LDS-DMA, a buffer store or (none today) an
+    atomic."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("hazard_scan", os.path.join(ROOT, "tools", "hazard_scan.py"))
+    hs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hs)
+    (isa,) = hs.compile_isa([os.path.join(hs.CSRC, "gemm_8p.hip")], jobs=1)
+    txt = open(isa).read()
+    kernels = re.findall(r"^(_ZN3vdr\S*gemm_8p_kernel\S*):\s*; @\S+\n(.*?); ScratchSize: (\d+)", txt, re.S | re.M)
+    assert len(kernels) == 4, [k[0] for k in kernels]
+    for name, body, scratch in kernels:
+        assert int(scratch) == 0, (name, scratch)
+        vmem = re.findall(r"^\s+((?:global|buffer|flat|scratch)_\w+)", body, re.M)
+        assert vmem and set(vmem) <= {"global_load_lds_dwordx4", "buffer_store_dwordx4"}, (name, sorted(set(vmem)))
