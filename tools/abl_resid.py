@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""What the residual epilogue costs: proj / fc2 shapes of the headline on a TUNING build, tile variant 26 complete and with its
+ablation encodings (126 = no epilogue, 826 = no output stores, 926 = both), interleaved.
+   python tools/abl_resid.py tools/ab_base/libvdr_tuning.so"""
 import ctypes as C, sys, torch
 lib = C.CDLL(sys.argv[1])
 lib.vdr_op_linear_packed.argtypes = [C.c_void_p] * 6 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
