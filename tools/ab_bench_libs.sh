@@ -1,6 +1,6 @@
 #!/bin/bash
-# Whole-forward A/B of several builds of libvdr.so: bench.py in alternating processes on one box (the builds sit under
-# ab/, git-ignored).   bash tools/ab_bench_libs.sh "pytest -k expr" lib1.so lib2.so ...   (the LAST library stays installed)
+# Whole-forward A/B of several builds of libvdr.so: bench.py in alternating processes on one box (the builds sit under tools/ab_base/,
+# git-ignored but not gpurun-ignored: ab/ does not travel).   bash tools/ab_bench_libs.sh "pytest -k expr" lib1.so lib2.so ...   (the LAST library stays installed)
 mkdir -p gpurun_out/ab
 L=vit-deep-radiomics_amd/vdr/libvdr.so
 K="$1"; shift
