@@ -8,7 +8,7 @@
 //   shape 1: 16x16x32 -- the same 32 queries as two 16-query column blocks, S^T as 14 x 2 tiles of 16 keys (112 registers),
 //            56 + 52 MFMAs of 16 cycles; a softmax row lives in 4 lanes instead of 2; V^T fragments by the same transposed LDS read
 // Same LDS bytes, same exponentials, same matrix-pipe cycles.  Prints cycles per item (shader clock) and the time per item.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o attn_shape attn_shape.hip && ./attn_shape [items]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o attn_shape attn_shape.hip && ./attn_shape [items] [mode]   (mode: see the kernel)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -41,6 +41,10 @@ __device__ void fill_images(char* smem, int tid, int nthr) {
 }
 
 // ---- shape 0: the kernel's own structure ---------------------------------------------------------------------------
+// abl (compile time): 4 = no MFMAs (one vector add per fragment instead), 8 = no exponentials, 16 = no LDS fragment reads (32: K only, 64: V only)
+// PF (compile time): 1 = the K fragments of tile t + 1 are requested before the 4 MFMAs of tile t, the V fragments of slice
+// it + 1 before the exponentials of slice it + 1 (both one full step ahead instead of just in time)
+template <int abl, int PF = 0>
 __device__ __forceinline__ float item_32(const char* smem, const bf16x8 (&qf)[4], int lane) {
   const int hh = lane >> 5, l31 = lane & 31, swz = (lane >> 1) & 7;
   const char* sK = smem + l31 * 128;
@@ -53,15 +57,34 @@ __device__ __forceinline__ float item_32(const char* smem, const bf16x8 (&qf)[4]
   const float sc = 0.125f * 1.44269504088896341f;
   f32x16 s[NT];
   __builtin_amdgcn_s_setprio(0);
+  bf16x8 kq[3][4];  // ring of PF + 1 tiles of K fragments
+  if constexpr (PF != 0) {
+#pragma unroll
+    for (int t0 = 0; t0 < PF; ++t0)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kq[t0][ks] = *reinterpret_cast<const bf16x8*>(sK + t0 * 32 * 128 + kch[ks]);
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[t][e] = (t == NT - 1 && (e & 3) + 8 * (e >> 2) + 4 * hh >= SEQ - (NT - 1) * 32) ? -INFINITY : 0.0f;
+    if constexpr (PF != 0) {
+      if (t + PF < NT) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kq[(t + PF) % (PF + 1)][ks] = *reinterpret_cast<const bf16x8*>(sK + (t + PF) * 32 * 128 + kch[ks]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * 32 * 128 + kch[ks]);
-      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      bf16x8 kf = qf[ks];
+      kf[0] = (bf16_t)(0.01f * (float)(t + 1));  // (ablations: a different operand per tile, or the 7 chains are one common subexpression)
+      if constexpr (PF != 0) kf = kq[t % (PF + 1)][ks];
+      else if constexpr (!(abl & 16) && !(abl & 32)) kf = *reinterpret_cast<const bf16x8*>(sK + t * 32 * 128 + kch[ks]);
+      if constexpr ((abl & 4) != 0) s[t][ks] += (float)kf[0];
+      else s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
     }
+    if constexpr (PF != 0) __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_s_setprio(2);
   float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -77,29 +100,50 @@ __device__ __forceinline__ float item_32(const char* smem, const bf16x8 (&qf)[4]
   for (int nd = 0; nd < 2; ++nd)
     for (int e = 0; e < 16; ++e) o[nd][e] = 0.0f;
   const f32x2 sc2 = {sc, sc}, nmb2 = {nmb, nmb};
+  bf16x4 vq[2][4];  // [slot][nd * 2 + (lo, hi)]
+  auto read_v = [&](int it, int slot) {
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd) {
+      vq[slot][2 * nd] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + vch[nd]));
+      vq[slot][2 * nd + 1] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + 8 * 128 + vch[nd]));
+    }
+  };
+  if constexpr (PF != 0) read_v(0, 0);
 #pragma unroll
   for (int it = 0; it < 13; ++it) {  // 13 slices of 16 keys hold the 197 keys
     const int t = it >> 1, s2 = it & 1;
     bf16x8 pf;
+    if constexpr (PF != 0) {
+      if (it + 1 < 13) read_v(it + 1, (it + 1) & 1);
+    }
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
       f32x2 x = {s[t][8 * s2 + j], s[t][8 * s2 + j + 1]};
       x = __builtin_elementwise_fma(x, sc2, nmb2);
-      f32x2 pv = {fast_exp2(x[0]), fast_exp2(x[1])};
+      f32x2 pv = x;
+      if constexpr (!(abl & 8)) pv = f32x2{fast_exp2(x[0]), fast_exp2(x[1])};
       lsum2 += pv;
       pf[j] = (bf16_t)pv[0];
       pf[j + 1] = (bf16_t)pv[1];
     }
 #pragma unroll
     for (int nd = 0; nd < 2; ++nd) {
-      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + vch[nd]));
-      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + 8 * 128 + vch[nd]));
-      bf16x8 vf;
-      for (int j = 0; j < 4; ++j) {
-        vf[j] = lo[j];
-        vf[4 + j] = hi[j];
+      bf16x8 vf = pf;
+      if constexpr (PF != 0) {
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = vq[it & 1][2 * nd][j];
+          vf[4 + j] = vq[it & 1][2 * nd + 1][j];
+        }
+      } else if constexpr (!(abl & 16) && !(abl & 64)) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + vch[nd]));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sV + it * 16 * 128 + 8 * 128 + vch[nd]));
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = lo[j];
+          vf[4 + j] = hi[j];
+        }
       }
-      o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
+      if constexpr ((abl & 4) != 0) o[nd][it] += (float)vf[0] * (float)pf[0];
+      else o[nd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[nd], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -209,8 +253,8 @@ __device__ __forceinline__ float item_16(const char* smem, const bf16x8 (&qf)[2]
   return acc;
 }
 
-template <int SHAPE>
-__global__ __launch_bounds__(512) void attn_shape_kernel(int items, float* sink, unsigned long long* cycles) {
+template <int SHAPE, int ABL = 0, int PF = 0>
+__global__ __launch_bounds__(512) void attn_shape_kernel(int items, float* sink, unsigned long long* cycles, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   fill_images(smem, tid, 512);
@@ -223,10 +267,17 @@ __global__ __launch_bounds__(512) void attn_shape_kernel(int items, float* sink,
       for (int e = 0; e < 8; ++e) q16[qb][kk][e] = (bf16_t)(0.01f * (float)(((16 * qb + (lane & 15)) * 7 + 32 * kk + 8 * (lane >> 4) + e) % 41 - 20));
   float acc = 0.0f;
   const unsigned long long t0 = __builtin_readcyclecounter();
+  // mode bits 2-4 (shape 0 only): ablations of item_32 (4 no MFMAs, 8 no exponentials, 16 no LDS fragment reads)
+  // mode bit 0: no barrier per item (the waves drift apart); bit 1: waves 4-6 -- the second wave of SIMDs 0-2 -- start half an
+  // item late (with bit 0: they stay half an item behind their SIMD partner)
+  if ((mode & 2) && wave >= 4) {
+    const unsigned long long w0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - w0 < 3800) __builtin_amdgcn_s_sleep(4);
+  }
   for (int it = 0; it < items; ++it) {
-    __builtin_amdgcn_s_barrier();  // (the kernel's one barrier per item)
+    if (!(mode & 1)) __builtin_amdgcn_s_barrier();  // (the kernel's one barrier per item)
     if (wave < 7) {
-      if (SHAPE == 0) acc += item_32(smem, q32, lane);
+      if (SHAPE == 0) acc += item_32<ABL, PF>(smem, q32, lane);
       else acc += item_16(smem, q16, lane);
     }
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(q32[ks]));
@@ -240,6 +291,7 @@ __global__ __launch_bounds__(512) void attn_shape_kernel(int items, float* sink,
 
 int main(int argc, char** argv) {
   const int items = argc > 1 ? atoi(argv[1]) : 48;
+  const int mode = argc > 2 ? atoi(argv[2]) : 0;
   int dev = 0;
   hipDeviceProp_t pr;
   CK(hipGetDeviceProperties(&pr, dev));
@@ -249,21 +301,27 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&sink, (size_t)grid * 512 * 4));
   CK(hipMalloc(&cyc, (size_t)grid * 8));
   const size_t lds = 2 * IMG;
-  auto k0 = attn_shape_kernel<0>, k1 = attn_shape_kernel<1>;
-  CK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   std::vector<float> hs((size_t)grid * 512);
   std::vector<unsigned long long> hc(grid);
-  for (int shape = 0; shape < 2; ++shape) {
+  typedef void (*kern_t)(int, float*, unsigned long long*, int);
+  struct Case { const char* name; kern_t fn; };
+  const Case cases[] = {{"32x32x16", attn_shape_kernel<0, 0>}, {"16x16x32", attn_shape_kernel<1, 0>},
+                        {"32x32x16, no MFMAs", attn_shape_kernel<0, 4>}, {"32x32x16, no exponentials", attn_shape_kernel<0, 8>},
+                        {"32x32x16, no LDS fragment reads", attn_shape_kernel<0, 16>}, {"32x32x16, no MFMAs, no exponentials", attn_shape_kernel<0, 12>},
+                        {"32x32x16, no MFMAs, no LDS reads", attn_shape_kernel<0, 20>}, {"32x32x16, no exponentials, no LDS reads", attn_shape_kernel<0, 24>},
+                        {"32x32x16, none of the three", attn_shape_kernel<0, 28>},
+                        {"32x32x16, fragments one step ahead", attn_shape_kernel<0, 0, 1>},
+                        {"32x32x16, K fragments two tiles ahead", attn_shape_kernel<0, 0, 2>},
+                        {"32x32x16, no K fragment reads", attn_shape_kernel<0, 32>}, {"32x32x16, no V fragment reads", attn_shape_kernel<0, 64>}};
+  for (const Case& cs : cases) {
+    CK(hipFuncSetAttribute((const void*)cs.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     double best = 1e30, sum0 = 0.0;
-    unsigned long long cmed = 0;
     for (int rep = 0; rep < 5; ++rep) {
       CK(hipEventRecord(a));
-      if (shape == 0) hipLaunchKernelGGL(k0, dim3(grid), dim3(512), lds, 0, items, sink, cyc);
-      else hipLaunchKernelGGL(k1, dim3(grid), dim3(512), lds, 0, items, sink, cyc);
+      hipLaunchKernelGGL(cs.fn, dim3(grid), dim3(512), lds, 0, items, sink, cyc, mode);
       CK(hipEventRecord(b));
       CK(hipEventSynchronize(b));
       float ms;
@@ -273,9 +331,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hs.data(), sink, hs.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < 448; ++i) sum0 += hs[i];
-    cmed = hc[grid / 2];
-    printf("shape %d (%s): %.1f us per launch of %d items per CU = %.2f us per item; %llu shader cycles per item (workgroup %d); checksum of workgroup 0: %.6f\n",
-           shape, shape == 0 ? "32x32x16" : "16x16x32", best * 1e3, items, best * 1e3 / items, cmed / (unsigned long long)items, grid / 2, sum0);
+    printf("mode %d %-40s: %.2f us per item, %llu shader cycles per item (workgroup %d); checksum %.6f\n", mode, cs.name, best * 1e3 / items,
+           hc[grid / 2] / (unsigned long long)items, grid / 2, sum0);
   }
   return 0;
 }
