@@ -160,6 +160,7 @@ __device__ __forceinline__ float item_32(const char* smem, const bf16x8 (&qf)[4]
 // S^T tile (kb, qb): keys 16 kb + 4 g + e (g = lane >> 4), query 16 qb + (lane & 15).
 // P^T operand of key chunk j (32 keys): the lane's 4 values of tile 2j and of tile 2j + 1 = keys 32 j + 4 g + e, 32 j + 16 + 4 g + e;
 // the V^T fragment is read in that key order: two transposed reads of 4 keys x 16 d per 16-lane group.
+template <int abl>
 __device__ __forceinline__ float item_16(const char* smem, const bf16x8 (&qf)[2][2], int lane) {
   const int c = lane & 15, g = lane >> 4;
   const char* sK = smem + c * 128;
@@ -185,7 +186,10 @@ __device__ __forceinline__ float item_16(const char* smem, const bf16x8 (&qf)[2]
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[kb][qb][e] = (kb * 16 + 4 * g + e >= SEQ) ? -INFINITY : 0.0f;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf[qb][kk], s[kb][qb], 0, 0, 0);
+      for (int kk = 0; kk < 2; ++kk) {
+        if constexpr ((abl & 4) != 0) s[kb][qb][kk] += (float)kf[kk][0];
+        else s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf[qb][kk], s[kb][qb], 0, 0, 0);
+      }
     }
   }
   __builtin_amdgcn_s_setprio(2);
@@ -236,7 +240,10 @@ __device__ __forceinline__ float item_16(const char* smem, const bf16x8 (&qf)[2]
         vf[4 + e] = hi[e];
       }
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
+      for (int qb = 0; qb < 2; ++qb) {
+        if constexpr ((abl & 4) != 0) o[db][qb][j & 3] += (float)vf[0] * (float)pf[qb][0];
+        else o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb], o[db][qb], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(512) void attn_shape_kernel(int items, float* sink,
     if (!(mode & 1)) __builtin_amdgcn_s_barrier();  // (the kernel's one barrier per item)
     if (wave < 7) {
       if (SHAPE == 0) acc += item_32<ABL, PF>(smem, q32, lane);
-      else acc += item_16(smem, q16, lane);
+      else acc += item_16<ABL>(smem, q16, lane);
     }
     for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(q32[ks]));
     for (int qb = 0; qb < 2; ++qb)
@@ -309,7 +316,7 @@ int main(int argc, char** argv) {
   typedef void (*kern_t)(int, float*, unsigned long long*, int);
   struct Case { const char* name; kern_t fn; };
   const Case cases[] = {{"32x32x16", attn_shape_kernel<0, 0>}, {"16x16x32", attn_shape_kernel<1, 0>},
-                        {"32x32x16, no MFMAs", attn_shape_kernel<0, 4>}, {"32x32x16, no exponentials", attn_shape_kernel<0, 8>},
+                        {"32x32x16, no MFMAs", attn_shape_kernel<0, 4>}, {"16x16x32, no MFMAs", attn_shape_kernel<1, 4>}, {"32x32x16, no exponentials", attn_shape_kernel<0, 8>},
                         {"32x32x16, no LDS fragment reads", attn_shape_kernel<0, 16>}, {"32x32x16, no MFMAs, no exponentials", attn_shape_kernel<0, 12>},
                         {"32x32x16, no MFMAs, no LDS reads", attn_shape_kernel<0, 20>}, {"32x32x16, no exponentials, no LDS reads", attn_shape_kernel<0, 24>},
                         {"32x32x16, none of the three", attn_shape_kernel<0, 28>},
